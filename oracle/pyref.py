@@ -1,0 +1,141 @@
+"""TEST INFRASTRUCTURE: ctypes binding of oracle/_ref/libsprl_ref*.so — the reference's own sources
+compiled in place by oracle/Makefile (see ref_harness.cpp).  Available only where the prebuilt
+.so exists (built in the container that has /root/reference; it travels to the GPU box).
+
+Only tests/, tests/golden/gen_golden.py and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_ref", "libsprl_ref.so")
+LIB_TORCH = os.path.join(HERE, "_ref", "libsprl_ref_torch.so")
+
+GEOM = {"othello": dict(cells=64, A=65, nsym=8), "c4": dict(cells=42, A=7, nsym=2)}
+
+
+def available(torch=False):
+    return os.path.exists(LIB_TORCH if torch else LIB)
+
+
+_libs = {}
+
+
+def lib(torch=False):
+    key = bool(torch)
+    if key not in _libs:
+        if torch:
+            import torch as _t  # noqa: F401  (loads libtorch so the harness' DT_NEEDED entries resolve)
+        L = C.CDLL(LIB_TORCH if torch else LIB)
+        L.ref_seed.argtypes = [C.c_uint64, C.c_int]
+        L.ref_uniform_int.argtypes = [C.c_int, C.c_int]
+        L.ref_uniform_float.restype = C.c_float
+        L.ref_dirichlet.argtypes = [C.c_float, C.c_int, C.c_void_p]
+        L.ref_sample_cdf.argtypes = [C.c_void_p, C.c_int]
+        L.ref_rng_raw.argtypes = [C.c_int, C.c_void_p]
+        for g in ("othello", "c4"):
+            getattr(L, f"ref_{g}_playout").argtypes = [C.c_uint64, C.c_int, C.c_int] + [C.c_void_p] * 6
+            getattr(L, f"ref_{g}_symmetrize").argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+            getattr(L, f"ref_{g}_selfplay").argtypes = [C.c_int] * 5 + [C.c_float] * 2 + [C.c_int] * 2 + \
+                [C.c_uint64] + [C.c_int] * 3 + [C.c_void_p] * 5
+            getattr(L, f"ref_{g}_search_trace").argtypes = [C.c_int] * 5 + [C.c_float] * 2 + [C.c_int] * 2 + \
+                [C.c_uint64, C.c_int] + [C.c_void_p] * 3
+        L.ref_othello_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.ref_othello_evaluate.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.ref_c4_known_answer.argtypes = [C.c_void_p]
+        L.ref_write_npy_f32.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
+        if torch:
+            L.ref_torch_othello_evaluate.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 5
+            for g in ("othello", "c4"):
+                getattr(L, f"ref_torch_{g}_selfplay").argtypes = [C.c_char_p] + [C.c_int] * 4 + [C.c_float] * 2 + \
+                    [C.c_uint64] + [C.c_int] * 3 + [C.c_void_p] * 6
+            L.ref_othello_run_worker.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int] * 5 + [C.c_float] * 2 + \
+                [C.c_uint64, C.c_int]
+            L.ref_c4_run_worker.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int] * 4 + [C.c_float] * 2 + \
+                [C.c_uint64, C.c_int]
+        _libs[key] = L
+    return _libs[key]
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def selfplay(game, eval_kind, num_games, traversals, max_batch, max_queue, eps, alpha, seed, stream_base=1,
+             per_game_stream=True, use_sym=1, add_noise=1, model_path=None):
+    g = GEOM[game]
+    cap = num_games * 130 * (g["nsym"] if use_sym else 1)
+    boards = np.zeros((cap, g["cells"]), np.int8)
+    players = np.zeros(cap, np.int8)
+    dists = np.zeros((cap, g["A"]), np.float32)
+    outcomes = np.zeros(cap, np.float32)
+    offs = np.zeros(num_games + 1, np.int32)
+    evals = None
+    if model_path is None:
+        n = getattr(lib(), f"ref_{game}_selfplay")(eval_kind, num_games, traversals, max_batch, max_queue, eps, alpha,
+                                                   use_sym, add_noise, seed, stream_base, int(per_game_stream), cap,
+                                                   vp(boards), vp(players), vp(dists), vp(outcomes), vp(offs))
+    else:
+        ne = np.zeros(1, np.int64)
+        n = getattr(lib(True), f"ref_torch_{game}_selfplay")(model_path.encode(), num_games, traversals, max_batch,
+                                                             max_queue, eps, alpha, seed, stream_base,
+                                                             int(per_game_stream), cap, vp(boards), vp(players),
+                                                             vp(dists), vp(outcomes), vp(offs), vp(ne))
+        evals = int(ne[0])
+    if n < 0:
+        raise RuntimeError("reference selfplay: capacity exceeded")
+    return dict(boards=boards[:n], players=players[:n], dists=dists[:n], outcomes=outcomes[:n], offsets=offs,
+                evals=evals)
+
+
+def search_trace(game, eval_kind, moves, traversals, max_batch, max_queue, eps, alpha, seed, stream=1,
+                 use_sym=1, add_noise=1):
+    g = GEOM[game]
+    stats = np.zeros((moves, 3, g["A"]), np.float32)
+    trav = np.zeros(moves, np.int32)
+    chosen = np.zeros(moves, np.int16)
+    m = getattr(lib(), f"ref_{game}_search_trace")(eval_kind, moves, traversals, max_batch, max_queue, eps, alpha,
+                                                   use_sym, add_noise, seed, stream, vp(stats), vp(trav), vp(chosen))
+    return stats[:m], trav[:m], chosen[:m]
+
+
+def playout(game, seed, stream=1, max_plies=200):
+    g = GEOM[game]
+    boards = np.zeros((max_plies, g["cells"]), np.int8)
+    players = np.zeros(max_plies, np.int8)
+    actions = np.zeros(max_plies, np.int16)
+    masks = np.zeros((max_plies, g["A"]), np.float32)
+    terminal = np.zeros(max_plies, np.int8)
+    rewards = np.zeros((max_plies, 2), np.float32)
+    n = getattr(lib(), f"ref_{game}_playout")(seed, stream, max_plies, vp(boards), vp(players), vp(actions),
+                                              vp(masks), vp(terminal), vp(rewards))
+    return dict(boards=boards[:n], players=players[:n], actions=actions[:n], masks=masks[:n],
+                terminal=terminal[:n], rewards=rewards[:n])
+
+
+def symmetrize(game, board, player, dist):
+    g = GEOM[game]
+    board = np.ascontiguousarray(board, np.int8)
+    dist = np.ascontiguousarray(dist, np.float32)
+    bo = np.zeros((g["nsym"], g["cells"]), np.int8)
+    do = np.zeros((g["nsym"], g["A"]), np.float32)
+    inv = np.zeros(g["nsym"], np.int8)
+    getattr(lib(), f"ref_{game}_symmetrize")(vp(board), int(player), vp(dist), vp(bo), vp(do), vp(inv))
+    return bo, do, inv
+
+
+def othello_evaluate(kind, boards, players, masks, model_path=None):
+    boards = np.ascontiguousarray(boards, np.int8)
+    players = np.ascontiguousarray(players, np.int8)
+    masks = np.ascontiguousarray(masks, np.float32)
+    n = len(players)
+    pol = np.zeros((n, 65), np.float32)
+    val = np.zeros(n, np.float32)
+    if model_path is None:
+        lib().ref_othello_evaluate(kind, n, vp(boards), vp(players), vp(masks), vp(pol), vp(val))
+    else:
+        lib(True).ref_torch_othello_evaluate(model_path.encode(), n, vp(boards), vp(players), vp(masks), vp(pol),
+                                             vp(val))
+    return pol, val
