@@ -35,6 +35,7 @@ def lib(torch=False):
         L.ref_dirichlet.argtypes = [C.c_float, C.c_int, C.c_void_p]
         L.ref_sample_cdf.argtypes = [C.c_void_p, C.c_int]
         L.ref_rng_raw.argtypes = [C.c_int, C.c_void_p]
+        L.ref_rng_state.restype = C.c_uint64
         for g in ("othello", "c4"):
             getattr(L, f"ref_{g}_playout").argtypes = [C.c_uint64, C.c_int, C.c_int] + [C.c_void_p] * 6
             getattr(L, f"ref_{g}_symmetrize").argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4

@@ -1,0 +1,188 @@
+"""Generate the golden fixtures in tests/golden/ from the reference itself.
+
+Runs ONLY in the container that has /root/reference: it drives oracle/_ref/libsprl_ref*.so (the
+reference's own C++ sources compiled in place by `make -C oracle ref ref_torch`) and, for G9 only,
+imports the reference's Python network definition.  The outputs are data (inputs + expected outputs);
+no reference source text is stored.
+
+    python tests/golden/gen_golden.py
+"""
+import hashlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from oracle import pyref  # noqa: E402
+
+SEED = 12345
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path)} bytes")
+
+
+def g6_rng():
+    L = pyref.lib()
+    out = {}
+    L.ref_seed(SEED, 1)
+    raw = np.zeros(1000, np.uint32)
+    L.ref_rng_raw(1000, pyref.vp(raw))
+    out["raw_seed12345_stream1"] = raw
+    L.ref_seed(987654321987, 77)
+    raw2 = np.zeros(64, np.uint32)
+    L.ref_rng_raw(64, pyref.vp(raw2))
+    out["raw_seed987654321987_stream77"] = raw2
+    L.ref_seed(SEED, 2)
+    ks = np.array([1, 2, 3, 4, 5, 7, 8, 10, 13, 33, 60, 65, 1000, 2 ** 31 - 1] * 16, np.int32)
+    out["uniform_int_k"] = ks
+    out["uniform_int"] = np.array([L.ref_uniform_int(0, int(k) - 1) for k in ks], np.int32)
+    out["uniform_float"] = np.array([L.ref_uniform_float() for _ in range(256)], np.float32)
+    for alpha, k in ((0.3, 10), (0.5, 7), (0.2, 50), (1.0, 5), (2.5, 6), (0.3, 1)):
+        rows = []
+        for _ in range(8):
+            v = np.zeros(k, np.float32)
+            L.ref_dirichlet(alpha, k, pyref.vp(v))
+            rows.append(v)
+        out[f"dirichlet_a{alpha}_k{k}"] = np.stack(rows)
+    cdf = np.cumsum(np.array([0, 0, 0.1, 0.2, 0, 0.3, 0.4, 0], np.float32)).astype(np.float32)
+    out["cdf"] = cdf
+    out["sample_cdf"] = np.array([L.ref_sample_cdf(pyref.vp(cdf), len(cdf)) for _ in range(256)], np.int32)
+    out["final_state"] = np.array([L.ref_rng_state()], np.uint64)
+    save("g6_rng.npz", **out)
+
+
+def g1_playouts():
+    out = {}
+    for game in ("othello", "c4"):
+        for i, seed in enumerate((11, 22, 33, 44)):
+            r = pyref.playout(game, seed, 1)
+            for k, v in r.items():
+                out[f"{game}_{i}_{k}"] = v
+            out[f"{game}_{i}_seed"] = np.array([seed], np.int64)
+    rw = np.zeros(2, np.float32)
+    ok = pyref.lib().ref_c4_known_answer(pyref.vp(rw))
+    out["c4_known_answer_ok"] = np.array([ok], np.int32)
+    out["c4_known_answer_rewards"] = rw
+    save("g1_playouts.npz", **out)
+
+
+def g2_symmetries():
+    rng = np.random.default_rng(5)
+    out = {}
+    for game, cells, A in (("othello", 64, 65), ("c4", 42, 7)):
+        board = rng.integers(-1, 2, cells).astype(np.int8)
+        dist = rng.random(A).astype(np.float32)
+        bo, do, inv = pyref.symmetrize(game, board, 1, dist)
+        out[f"{game}_board"] = board
+        out[f"{game}_dist"] = dist
+        out[f"{game}_boards_out"] = bo
+        out[f"{game}_dists_out"] = do
+        out[f"{game}_inverse"] = inv
+    save("g2_symmetries.npz", **out)
+
+
+def g4_search():
+    out = {}
+    for game, alpha in (("othello", 0.3), ("c4", 0.5)):
+        for kind in ((0, 1) if game == "othello" else (0,)):
+            for (mb, mq) in ((8, 4), (1, 1)):
+                st, tr, ch = pyref.search_trace(game, kind, 3, 200, mb, mq, 0.25, alpha, SEED, 1)
+                key = f"{game}_k{kind}_b{mb}q{mq}"
+                out[key + "_stats"] = st
+                out[key + "_trav"] = tr
+                out[key + "_chosen"] = ch
+    # Q8 demonstration: start-position priors per forced symmetry cannot be forced from outside; instead
+    # keep a no-noise trace whose root priors show zeros where the drawn symmetry moved the mask (Q1).
+    st, tr, ch = pyref.search_trace("othello", 0, 1, 16, 8, 4, 0.25, 0.3, SEED, 1, use_sym=1, add_noise=0)
+    out["othello_nonoise_stats"] = st
+    save("g4_search.npz", **out)
+
+
+def g5_games():
+    out = {}
+    r = pyref.selfplay("othello", 0, 2, 60, 8, 4, 0.25, 0.3, SEED, 1, True)
+    for k in ("boards", "players", "dists", "outcomes", "offsets"):
+        out["oth_random_" + k] = r[k]
+    r = pyref.selfplay("othello", 1, 1, 40, 8, 4, 0.25, 0.3, SEED, 5, True)
+    for k in ("boards", "players", "dists", "outcomes", "offsets"):
+        out["oth_heur_" + k] = r[k]
+    r = pyref.selfplay("c4", 0, 4, 100, 8, 4, 0.25, 0.5, SEED, 1, True)
+    for k in ("boards", "players", "dists", "outcomes", "offsets"):
+        out["c4_random_" + k] = r[k]
+    # single global stream over several games (what the reference worker really does)
+    r = pyref.selfplay("c4", 0, 3, 100, 8, 4, 0.25, 0.5, SEED, 9, False)
+    for k in ("boards", "players", "dists", "outcomes", "offsets"):
+        out["c4_single_stream_" + k] = r[k]
+    r = pyref.selfplay("othello", 0, 1, 30, 1, 1, 0.25, 0.3, SEED, 3, True, use_sym=0, add_noise=0)
+    for k in ("boards", "players", "dists", "outcomes", "offsets"):
+        out["oth_nosym_b1q1_" + k] = r[k]
+    save("g5_games.npz", **out)
+
+    # worker byte streams (runWorker + vendored npy writer)
+    L = pyref.lib(True)
+    w = {}
+    with tempfile.TemporaryDirectory() as td:
+        L.ref_c4_run_worker(b"gold", td.encode(), 3, 100, 8, 4, 0.25, 0.5, SEED, 1)
+        L.ref_othello_run_worker(b"goldoth", td.encode(), 0, 1, 30, 8, 4, 0.25, 0.3, SEED, 1)
+        for run in ("gold", "goldoth"):
+            for part in ("states", "distributions", "outcomes"):
+                b = open(os.path.join(td, f"{run}_iteration_0_{part}.npy"), "rb").read()
+                w[f"{run}_{part}"] = np.frombuffer(b, np.uint8)
+                print(run, part, len(b), hashlib.sha256(b).hexdigest()[:16])
+    save("g5_worker_npy.npz", **w)
+
+
+def g7_g9_network():
+    import torch
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    from src.networks.grid_networks import BasicGridNetwork  # reference definition, this container only
+
+    torch.manual_seed(3)
+    ref_net = BasicGridNetwork(8, 8, 65, 1, 1, 8).eval()
+    with torch.no_grad():
+        for m in ref_net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0.0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    x = (torch.rand(5, 3, 8, 8) > 0.6).float()
+    with torch.no_grad():
+        logits, value = ref_net(x)
+    out = {"input": x.numpy(), "logits": logits.numpy(), "value": value.numpy()}
+    for k, v in ref_net.state_dict().items():
+        out["sd::" + k] = v.numpy()
+    save("g9_network.npz", **out)
+
+    # G7: the reference GridNetwork::evaluate (LibTorch CPU) through a traced model of OUR module
+    from sprl_amd.network import GridResNet, trace_to_file
+    net = GridResNet(8, 8, 65, 1, 1, 8)
+    net.load_state_dict(ref_net.state_dict())
+    net.eval()
+    with tempfile.TemporaryDirectory() as td:
+        path = trace_to_file(net, os.path.join(td, "tiny.pt"), "othello")
+        po = pyref.playout("othello", 77, 1)
+        idx = [0, 5, 17, 30, len(po["players"]) - 2]
+        boards, players, masks = po["boards"][idx], po["players"][idx], po["masks"][idx].copy()
+        masks[3, :] = 0.0
+        masks[3, 64] = 1.0            # pass-only mask
+        pol, val = pyref.othello_evaluate(0, boards, players, masks, model_path=path)
+    save("g7_decode.npz", boards=boards, players=players, masks=masks, policy=pol, value=val)
+
+
+if __name__ == "__main__":
+    assert pyref.available() and pyref.available(True), "run `make -C oracle ref ref_torch` first"
+    g6_rng()
+    g1_playouts()
+    g2_symmetries()
+    g4_search()
+    g5_games()
+    g7_g9_network()

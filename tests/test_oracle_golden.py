@@ -1,0 +1,215 @@
+"""The CPU oracle (oracle/sprl_oracle.c) against the golden vectors produced from the reference itself
+(tests/golden/gen_golden.py) and, where the prebuilt reference library is present, against live runs.
+Integer/byte/float results are compared bit-for-bit (libm math mode = the reference's own libm calls)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from oracle import pyref
+
+SEED = 12345
+GAMES = {"othello": po.GAME_OTHELLO, "c4": po.GAME_C4}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_g6_rng_streams(golden):
+    g = golden("g6_rng.npz")
+    assert (po.rng_stream(SEED, 1, 1000) == g["raw_seed12345_stream1"]).all()
+    assert (po.rng_stream(987654321987, 77, 64) == g["raw_seed987654321987_stream77"]).all()
+
+
+def test_g6_distributions(golden):
+    g = golden("g6_rng.npz")
+    L = po.lib()
+    r = po.RNG()
+    L.orc_rng_seed(C.byref(r), SEED, 2)
+    got = np.array([L.orc_uniform_int(C.byref(r), 0, int(k) - 1) for k in g["uniform_int_k"]], np.int32)
+    assert (got == g["uniform_int"]).all()
+    fl = np.array([L.orc_uniform_float(C.byref(r)) for _ in range(256)], np.float32)
+    assert (bits(fl) == bits(g["uniform_float"])).all()
+    for alpha, k in ((0.3, 10), (0.5, 7), (0.2, 50), (1.0, 5), (2.5, 6), (0.3, 1)):
+        want = g[f"dirichlet_a{alpha}_k{k}"]
+        for row in want:
+            v = np.zeros(k, np.float32)
+            L.orc_dirichlet(C.byref(r), alpha, k, po.vp(v), po.MATH_LIBM)
+            assert (bits(v) == bits(row)).all(), (alpha, k)
+    cdf = g["cdf"]
+    sc = np.array([L.orc_sample_cdf(C.byref(r), po.vp(cdf), len(cdf)) for _ in range(256)], np.int32)
+    assert (sc == g["sample_cdf"]).all()
+    assert set(sc.tolist()) <= {2, 3, 5, 6}          # zero-probability entries are never sampled
+    assert r.state == int(g["final_state"][0])       # same number of engine draws consumed
+
+
+@pytest.mark.parametrize("game", ["othello", "c4"])
+def test_g1_playouts(golden, game):
+    g = golden("g1_playouts.npz")
+    for i in range(4):
+        seed = int(g[f"{game}_{i}_seed"][0])
+        r = po.playout(GAMES[game], seed, 1)
+        for k in ("boards", "players", "actions", "terminal"):
+            assert (r[k] == g[f"{game}_{i}_{k}"]).all(), (game, i, k)
+        assert (bits(r["masks"]) == bits(g[f"{game}_{i}_masks"])).all()
+        assert (r["rewards"] == g[f"{game}_{i}_rewards"]).all()
+        assert r["terminal"][-1] == 1
+
+
+def test_g10_c4_known_answer(golden):
+    """cpp/tests/test_c4.cpp:5-26 restated: actions {3,3,4,4,2,3,1} end in a win for player ZERO."""
+    g = golden("g1_playouts.npz")
+    assert int(g["c4_known_answer_ok"][0]) == 1 and g["c4_known_answer_rewards"].tolist() == [1.0, -1.0]
+    board = -np.ones(42, np.int8)
+    mask = np.ones(7, np.float32)
+    player, term, winner = 0, 0, -1
+    for a in (3, 3, 4, 4, 2, 3, 1):
+        assert term == 0 and winner == -1
+        board, mask, term, winner = po.step(po.GAME_C4, board, player, mask, a)
+        player = 1 - player
+    assert term == 1 and winner == 0
+    assert (mask == 0).all()                          # ConnectFourNode.cpp:69-71
+
+
+@pytest.mark.parametrize("game", ["othello", "c4"])
+def test_g2_symmetries(golden, game):
+    g = golden("g2_symmetries.npz")
+    bo, do, inv = po.symmetrize(GAMES[game], g[f"{game}_board"], g[f"{game}_dist"])
+    assert (bo == g[f"{game}_boards_out"]).all()
+    assert (bits(do) == bits(g[f"{game}_dists_out"])).all()
+    assert (inv == g[f"{game}_inverse"]).all()
+    # inverse really inverts
+    for s in range(len(inv)):
+        b2, _, _ = po.symmetrize(GAMES[game], bo[s], do[s])
+        assert (b2[inv[s]] == g[f"{game}_board"]).all()
+
+
+@pytest.mark.parametrize("key,game,kind,mb,mq,alpha", [
+    ("othello_k0_b8q4", "othello", 0, 8, 4, 0.3), ("othello_k0_b1q1", "othello", 0, 1, 1, 0.3),
+    ("othello_k1_b8q4", "othello", 1, 8, 4, 0.3), ("othello_k1_b1q1", "othello", 1, 1, 1, 0.3),
+    ("c4_k0_b8q4", "c4", 0, 8, 4, 0.5), ("c4_k0_b1q1", "c4", 0, 1, 1, 0.5)])
+def test_g4_search_trace(golden, key, game, kind, mb, mq, alpha):
+    g = golden("g4_search.npz")
+    cfg = po.make_config(GAMES[game], 200, max_batch=mb, max_queue=mq, dir_alpha=alpha, eval_kind=kind)
+    st, tr, ch = po.search_trace(cfg, 3, SEED, 1)
+    assert (tr == g[key + "_trav"]).all() and (ch == g[key + "_chosen"]).all()
+    assert (bits(st) == bits(g[key + "_stats"])).all()
+
+
+def test_g8_q1_wrong_frame_mask(golden):
+    """without noise the start-position priors are 0.25 x4 or all zero depending on the symmetry
+    drawn for the root evaluation; the oracle reproduces whichever the reference drew."""
+    g = golden("g4_search.npz")
+    cfg = po.make_config(po.GAME_OTHELLO, 16, add_noise=0)
+    st, _, _ = po.search_trace(cfg, 1, SEED, 1)
+    assert (bits(st) == bits(g["othello_nonoise_stats"])).all()
+    pri = st[0, 2]
+    assert set(np.unique(pri).tolist()) <= {0.0, 0.25}
+
+
+CASES = [
+    ("oth_random", po.GAME_OTHELLO, dict(num_traversals=60), 2, 1, True),
+    ("oth_heur", po.GAME_OTHELLO, dict(num_traversals=40, eval_kind=po.EVAL_HEURISTIC), 1, 5, True),
+    ("c4_random", po.GAME_C4, dict(num_traversals=100), 4, 1, True),
+    ("c4_single_stream", po.GAME_C4, dict(num_traversals=100), 3, 9, False),
+    ("oth_nosym_b1q1", po.GAME_OTHELLO, dict(num_traversals=30, max_batch=1, max_queue=1, use_sym=0, add_noise=0),
+     1, 3, True),
+]
+
+
+@pytest.mark.parametrize("name,game,kw,ngames,stream,per_game", CASES)
+def test_g5_whole_games(golden, name, game, kw, ngames, stream, per_game):
+    g = golden("g5_games.npz")
+    cfg = po.make_config(game, **kw)
+    r = po.selfplay(cfg, ngames, SEED, stream, per_game)
+    assert (r["offsets"] == g[name + "_offsets"]).all()
+    assert (r["boards"] == g[name + "_boards"]).all()
+    assert (r["players"] == g[name + "_players"]).all()
+    assert (bits(r["dists"]) == bits(g[name + "_dists"])).all()
+    assert (r["outcomes"] == g[name + "_outcomes"]).all()
+    s = r["stats"]
+    assert s["games"] == ngames and s["traversals"] >= s["plies"] * cfg.num_traversals
+
+
+@pytest.mark.parametrize("run,game,ngames,trav,alpha", [("gold", po.GAME_C4, 3, 100, 0.5),
+                                                        ("goldoth", po.GAME_OTHELLO, 1, 30, 0.3)])
+def test_g5_worker_npy_bytes(golden, tmp_path, run, game, ngames, trav, alpha):
+    """Byte-identical .npy streams vs the reference's runWorker + vendored npy writer."""
+    g = golden("g5_worker_npy.npz")
+    cfg = po.make_config(game, trav, dir_alpha=alpha)
+    r = po.selfplay(cfg, ngames, SEED, 1, per_game_stream=False)
+    prefix = str(tmp_path / f"{run}_iteration_0")
+    assert po.write_records(cfg, prefix, r) == 0
+    for part in ("states", "distributions", "outcomes"):
+        got = np.frombuffer(open(f"{prefix}_{part}.npy", "rb").read(), np.uint8)
+        assert got.shape == g[f"{run}_{part}"].shape and (got == g[f"{run}_{part}"]).all(), part
+        arr = np.load(f"{prefix}_{part}.npy")
+        assert arr.dtype == np.float32 and arr.shape[0] == len(r["players"])
+
+
+def test_g7_decode(golden):
+    """GridNetwork::evaluate post-processing (exp, wrong-frame mask, sum==0 -> uniform, *1/sum)."""
+    import torch
+    from sprl_amd.network import GridResNet
+    g7, g9 = golden("g7_decode.npz"), golden("g9_network.npz")
+    net = GridResNet(8, 8, 65, 1, 1, 8)
+    net.load_state_dict({k[4:]: torch.from_numpy(g9[k]) for k in g9.files if k.startswith("sd::")})
+    net.eval()
+
+    def fwd(x):
+        with torch.no_grad():
+            lo, va = net(torch.from_numpy(x))
+        return lo.numpy(), va.numpy()
+
+    cb = po.make_forward(fwd, po.GAME_OTHELLO)
+    cfg = po.make_config(po.GAME_OTHELLO, 1, eval_kind=po.EVAL_CALLBACK, forward=cb)
+    pol, val = po.evaluate(cfg, g7["boards"], g7["players"], g7["masks"])
+    np.testing.assert_allclose(pol, g7["policy"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(val, g7["value"], rtol=0, atol=1e-6)
+    assert pol[3, 64] == 1.0 and pol[3, :64].sum() == 0.0
+    # all-masked-out logits underflow -> uniform fallback
+    A = 65
+    logits = np.full(A, -200.0, np.float32)
+    mask = np.zeros(A, np.float32)
+    mask[[3, 9, 40]] = 1.0
+    out = np.zeros(A, np.float32)
+    po.lib().orc_decode_policy(A, po.vp(logits), po.vp(mask), po.vp(out), po.MATH_LIBM)
+    assert out[[3, 9, 40]].tolist() == [np.float32(1.0) / 3] * 3 and out.sum() == pytest.approx(1.0)
+    # overflow: exp(+inf-ish) -> inf/inf = nan is what the reference computes; we just must not crash
+    logits[:] = 100.0
+    po.lib().orc_decode_policy(A, po.vp(logits), po.vp(mask), po.vp(out), po.MATH_LIBM)
+
+
+def test_g9_network_contract(golden):
+    """Our GridResNet == the reference BasicGridNetwork on the captured state_dict (1e-5 abs)."""
+    import torch
+    from sprl_amd.network import GridResNet
+    g9 = golden("g9_network.npz")
+    net = GridResNet(8, 8, 65, 1, 1, 8)
+    missing = net.load_state_dict({k[4:]: torch.from_numpy(g9[k]) for k in g9.files if k.startswith("sd::")})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net.eval()
+    with torch.no_grad():
+        lo, va = net(torch.from_numpy(g9["input"]))
+    np.testing.assert_allclose(lo.numpy(), g9["logits"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(va.numpy(), g9["value"], atol=1e-5, rtol=0)
+    assert va.shape == (5, 1)
+
+
+@pytest.mark.skipif(not pyref.available(), reason="prebuilt reference library not present")
+@pytest.mark.parametrize("game,kind,trav,mb,mq,alpha,ngames", [
+    ("othello", 0, 200, 8, 4, 0.3, 2), ("othello", 1, 100, 8, 4, 0.3, 2), ("othello", 0, 64, 1, 1, 0.3, 1),
+    ("c4", 0, 100, 8, 4, 0.5, 6), ("c4", 0, 512, 8, 4, 0.5, 2)])
+def test_live_reference_whole_games(game, kind, trav, mb, mq, alpha, ngames):
+    """Fresh seeds (not in the fixtures): oracle == reference build, bit for bit."""
+    seed = 424242 + trav
+    r = pyref.selfplay(game, kind, ngames, trav, mb, mq, 0.25, alpha, seed, 3, True)
+    cfg = po.make_config(GAMES[game], trav, max_batch=mb, max_queue=mq, dir_alpha=alpha, eval_kind=kind)
+    o = po.selfplay(cfg, ngames, seed, 3, True)
+    assert (o["offsets"] == r["offsets"]).all()
+    for k in ("boards", "players", "outcomes"):
+        assert (o[k] == r[k]).all()
+    assert (bits(o["dists"]) == bits(r["dists"])).all()
