@@ -1,0 +1,139 @@
+/* sprl_amd.h — C ABI of the MI355X-native self-play engine (libsprl_amd.so).
+ *
+ * Drop-in boundary for the reference's self-play worker path.  The reference has no FFI; each entry
+ * point below replaces the C++ template interface cited next to it (paths relative to
+ * /root/reference/cpp/src).  Plain pointers and sizes only — no torch or HIP types.  See INTEGRATION.md
+ * for the reference-side binding a maintainer would add.
+ *
+ * Conventions: every call returns 0 on success or a negative SPRL_E_* code and records a message
+ * retrievable with sprl_last_error() (thread-local).  No exception crosses the boundary.  One engine
+ * per GPU; calls on one engine must be serialised by the caller; engines on different GPUs are
+ * independent.  The engine REQUIRES a gfx950 device: there is no CPU fallback, creation fails loudly.
+ */
+#ifndef SPRL_AMD_H
+#define SPRL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPRL_E_CONFIG   (-1)  /* bad configuration value */
+#define SPRL_E_MODEL    (-2)  /* model file could not be loaded / evaluator plugin missing */
+#define SPRL_E_NODEPOOL (-3)  /* a game's node arena overflowed (raise node_cap / spare_arenas) */
+#define SPRL_E_DEVICE   (-4)  /* HIP error, no device, allocation failure */
+#define SPRL_E_STATE    (-5)  /* call sequence error */
+#define SPRL_E_IO       (-6)  /* file could not be written */
+#define SPRL_E_LIMIT    (-7)  /* game longer than max_plies / line deeper than the path buffer */
+
+enum { SPRL_OTHELLO = 0, SPRL_CONNECT_FOUR = 1 };
+/* evaluator kinds: the reference's RandomNetwork (networks/RandomNetwork.hpp:15-57), OthelloHeuristic
+ * (networks/OthelloHeuristic.cpp:5-53) and GridNetwork on a traced TorchScript file
+ * (networks/GridNetwork.hpp:37-145) */
+enum { SPRL_EVAL_RANDOM = 0, SPRL_EVAL_HEURISTIC = 1, SPRL_EVAL_NETWORK = 2 };
+/* the reference applies the un-symmetrised action mask to the symmetrised policy
+ * (uct/UCTTree.hpp:138,146-147,152).  REFERENCE reproduces that; SYMMETRISED is the repaired behaviour. */
+enum { SPRL_MASK_REFERENCE = 0, SPRL_MASK_SYMMETRISED = 1 };
+
+/* Replaces the compile-time constants of OTHWorker.cpp:12-28 / C4Worker.cpp:11-27 / constants.hpp:4-10
+ * and the arguments of runIteration (selfplay/SelfPlay.hpp:204-209). */
+typedef struct sprl_config {
+    int32_t game;              /* SPRL_OTHELLO | SPRL_CONNECT_FOUR */
+    int32_t device;            /* HIP device ordinal */
+    int32_t concurrent_games;  /* game slots resident in HBM (one wavefront each) */
+    int32_t num_traversals;    /* UCT traversals per move, lower bound (SelfPlay.hpp:100) */
+    int32_t max_batch;         /* traversals per search batch (UCTTree.hpp:82) */
+    int32_t max_queue;         /* network leaves per search batch, <= 8 (UCTTree.hpp:108) */
+    float dir_eps;             /* Dirichlet mixing weight (UCTNode.hpp:341-343) */
+    float dir_alpha;           /* Dirichlet concentration */
+    float u_weight;            /* constants.hpp:6 */
+    int32_t early_cutoff;      /* constants.hpp:8 */
+    float early_exp;           /* constants.hpp:9 */
+    float rest_exp;            /* constants.hpp:10 */
+    int32_t use_symmetry;      /* symmetrizer != nullptr */
+    int32_t add_noise;         /* runIteration's addNoise */
+    int32_t mask_frame;        /* SPRL_MASK_* */
+    int32_t node_cap;          /* nodes per game arena (1 KiB each), <= 65535; 0 = default */
+    int32_t spare_arenas;      /* arenas kept free for compaction; 0 = default */
+    int32_t max_plies;         /* record capacity per game; 0 = default */
+    uint64_t seed;             /* game g uses Random(seed, stream_base + g) (utils/random.hpp:92-103) */
+    int32_t stream_base;       /* must be >= 1 */
+    int32_t profile;           /* 1: time every tree-kernel launch with HIP events on its stream */
+} sprl_config;
+
+/* Fills `cfg` with the reference worker's constants for `game` (OTHWorker.cpp:24-28, C4Worker.cpp:23-27,
+ * constants.hpp:6-10), 800 traversals, 4096 concurrent games, seed 1. */
+int sprl_config_default(int32_t game, sprl_config* cfg);
+
+typedef struct sprl_engine sprl_engine;
+
+/* UCTTree + selfPlay state for `concurrent_games` games on one GPU (uct/UCTTree.hpp:38-53). */
+int sprl_engine_create(const sprl_config* cfg, sprl_engine** out);
+void sprl_engine_destroy(sprl_engine* e);
+
+/* INetwork selection (selfplay/GridWorker.hpp:123-131).  `model` is "random", "heuristic" or the path of a
+ * traced TorchScript module forward(float32[B,2H+1,R,C]) -> (float32[B,A], float32[B,1])
+ * (networks/GridNetwork.hpp:99-102), which is evaluated on the GPU through LibTorch-ROCm. */
+int sprl_engine_set_model(sprl_engine* e, const char* model);
+
+/* Alternative evaluator hook: `fn` is called once per search round with DEVICE pointers
+ * planes float32[batch][2H+1][R][C] -> logits float32[batch][A], value float32[batch]; it must enqueue its
+ * work on the HIP null stream (or synchronise before returning). */
+typedef int (*sprl_forward_fn)(void* user, const float* planes, int32_t batch, float* logits, float* value);
+int sprl_engine_set_forward(sprl_engine* e, sprl_forward_fn fn, void* user);
+
+/* Compact self-play records of a run, host memory owned by the library until sprl_records_free.
+ * Sample order = the reference's: game-major, ply-major (SelfPlay.hpp:86-92,127-133,154-163).  */
+typedef struct sprl_records {
+    int32_t game, num_games, rows, cols, cells, actions, nsym, use_symmetry;
+    int64_t total_plies;
+    const int32_t* ply_offset;  /* [num_games + 1] */
+    const int8_t* boards;       /* [total_plies][cells]  -1 empty, 0, 1 (GridState.hpp:18-22) */
+    const int8_t* movers;       /* [total_plies] */
+    const float* pdfs;          /* [total_plies][actions] tempered visit pdf (SelfPlay.hpp:111-121) */
+    const int8_t* winners;      /* [num_games] -1 draw, 0, 1 */
+    void* owner_;
+} sprl_records;
+
+/* runIteration (selfplay/SelfPlay.hpp:204-248): plays `num_games` games to the end. Blocking. */
+int sprl_engine_run(sprl_engine* e, int32_t num_games, sprl_records* out);
+
+/* The same in pieces (bench / pipelining): begin, then step until *games_done == num_games, then collect.
+ * One step = `rounds` search rounds for every resident game (select kernel [+ network forward] + finish). */
+int sprl_engine_begin(sprl_engine* e, int32_t num_games);
+int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_t* active_slots);
+int sprl_engine_collect(sprl_engine* e, sprl_records* out);
+void sprl_records_free(sprl_records* r);
+
+typedef struct sprl_stats {
+    int64_t games, plies, traversals, levels, expansions, nn_evals, terminal_hits, gray_hits, dup_hits,
+        nodes_created, compactions, max_nodes_in_arena;
+    int64_t rounds, kernel_launches, nn_batches;
+    double seconds_total;      /* wall time inside run/step */
+    double kernel_ms;          /* sum of tree-kernel durations (HIP events; profile=1) */
+    double nn_ms;              /* sum of network forward durations (HIP events; profile=1) */
+    int64_t hbm_bytes;         /* device memory allocated by the engine */
+} sprl_stats;
+int sprl_engine_stats(sprl_engine* e, sprl_stats* out);
+
+/* Expanded training samples exactly as the reference worker emits them (selfplay/GridWorker.hpp:146-196):
+ * states float32[N][2H+1][R][C], distributions float32[N][A], outcomes float32[N], N = plies * nsym.
+ * Buffers are caller-provided (sizes from sprl_records_num_samples). */
+int64_t sprl_records_num_samples(const sprl_records* r);
+int sprl_records_expand(const sprl_records* r, float* states, float* distributions, float* outcomes);
+/* int8 boards + mover per sample instead of planes (for comparisons) */
+int sprl_records_expand_boards(const sprl_records* r, int8_t* boards, int8_t* players);
+
+/* utils/npy.hpp:430-476 + GridWorker.hpp:173-196: writes <prefix>_states.npy, _distributions.npy,
+ * _outcomes.npy (byte-identical headers; temp file + rename, outcomes last). */
+int sprl_write_npy(const char* path_prefix, const sprl_records* r);
+
+const char* sprl_last_error(void);
+/* 1 when the library was built for gfx950 and a usable device is present */
+int sprl_device_available(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,32 @@
+// backend.h — the seam between the engine host code and the device runtime.
+// The product implements it with HIP for gfx950 (backend_hip.hip).  tests/emu implements it on the CPU SIMT
+// emulator for kernel-logic checks; that build is never shipped and the product has no fallback path.
+#ifndef SPRL_BACKEND_H
+#define SPRL_BACKEND_H
+
+#include <stddef.h>
+
+#include <string>
+
+#include "engine_types.h"
+
+namespace be {
+bool available(std::string* why);
+int init(int device, std::string* err);
+void* dmalloc(size_t bytes);
+void dfree(void* p);
+int h2d(void* dst, const void* src, size_t n);
+int d2h(void* dst, const void* src, size_t n);
+int dmemset(void* dst, int v, size_t n);
+int sync();
+// one 64-lane wavefront per game slot, on the null stream
+int launch_step(int game, const EngineParams& P);
+// event pairs on the null stream (profile mode); returns milliseconds between the two marks
+void* mark();
+double elapsed_ms(void* a, void* b);   // synchronises on b
+void mark_free(void* m);
+const char* name();
+const char* last_error();
+}  // namespace be
+
+#endif

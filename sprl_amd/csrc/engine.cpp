@@ -1,0 +1,605 @@
+// engine.cpp — host side of the self-play engine: the C ABI of include/sprl_amd.h.
+//
+// Mirrors the reference's worker-side objects behind a C boundary:
+//   sprl_engine_create/run  <->  runIteration / selfPlay / UCTTree      (selfplay/SelfPlay.hpp, uct/UCTTree.hpp)
+//   sprl_engine_set_model   <->  GridNetwork / RandomNetwork selection  (selfplay/GridWorker.hpp:123-131)
+//   sprl_records_expand     <->  symmetrised record assembly            (SelfPlay.hpp:86-92,127-133,151-189)
+//   sprl_write_npy          <->  plane encoding + npy writer            (GridWorker.hpp:146-196, utils/npy.hpp:430-476)
+// The search itself runs in the gfx950 kernels (step_kernel.h); this file only owns buffers and the round loop.
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/sprl_amd.h"
+#include "backend.h"
+#include "engine_types.h"
+#include "games.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+struct Geom {
+    int rows, cols, cells, A, nsym, max_depth, default_max_plies;
+};
+
+Geom geom_of(int game) {
+    if (game == SPRL_CONNECT_FOUR)
+        return { ConnectFour::ROWS, ConnectFour::COLS, ConnectFour::CELLS, ConnectFour::A, ConnectFour::NSYM,
+                 ConnectFour::MAX_DEPTH, 48 };
+    return { Othello::ROWS, Othello::COLS, Othello::CELLS, Othello::A, Othello::NSYM, Othello::MAX_DEPTH, 128 };
+}
+
+int map_cell(int game, int sym, int cell) {
+    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_cell(sym, cell) : Othello::map_cell(sym, cell);
+}
+int map_action(int game, int sym, int a) {
+    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_action(sym, a) : Othello::map_action(sym, a);
+}
+
+// LibTorch-ROCm evaluator plugin (libsprl_amd_torch.so), resolved lazily so the core has no torch dependency
+struct TorchPlugin {
+    void* lib = nullptr;
+    void* (*load)(const char*, int, char*, int) = nullptr;
+    int (*forward)(void*, const float*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
+    void (*release)(void*) = nullptr;
+};
+
+struct RecordsOwner {
+    std::vector<int32_t> ply_offset;
+    std::vector<int8_t> boards, movers, winners;
+    std::vector<float> pdfs;
+};
+
+}  // namespace
+
+struct sprl_engine {
+    sprl_config cfg;
+    Geom g;
+    EngineParams P;          // device pointers + parameters, passed by value to the kernel
+    int eval_kind = SPRL_EVAL_RANDOM;
+    sprl_forward_fn forward_cb = nullptr;
+    void* forward_user = nullptr;
+    TorchPlugin torch;
+    void* torch_model = nullptr;
+    int num_games = 0;
+    bool running = false;
+    size_t hbm_bytes = 0;
+    std::vector<void*> allocs;
+    float* nn_logits = nullptr;
+    float* nn_value = nullptr;
+    // accounting
+    int64_t rounds = 0, launches = 0, nn_batches = 0;
+    double seconds = 0.0, kernel_ms = 0.0, nn_ms = 0.0;
+    std::vector<void*> marks;  // k0,k1,(n0,n1) per round, resolved lazily
+    std::vector<int> mark_kind;
+};
+
+namespace {
+
+void* dev_alloc(sprl_engine* e, size_t bytes) {
+    void* p = be::dmalloc(bytes ? bytes : 16);
+    if (p) {
+        e->allocs.push_back(p);
+        e->hbm_bytes += bytes;
+    }
+    return p;
+}
+
+void resolve_marks(sprl_engine* e) {
+    for (size_t i = 0; i + 1 < e->marks.size(); i += 2) {
+        double ms = be::elapsed_ms(e->marks[i], e->marks[i + 1]);
+        if (e->mark_kind[i / 2] == 0) e->kernel_ms += ms;
+        else e->nn_ms += ms;
+        be::mark_free(e->marks[i]);
+        be::mark_free(e->marks[i + 1]);
+    }
+    e->marks.clear();
+    e->mark_kind.clear();
+}
+
+int load_torch_plugin(sprl_engine* e) {
+    if (e->torch.lib) return 0;
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr((void*)&sprl_config_default, &info) && info.dli_fname) {
+        std::string f(info.dli_fname);
+        size_t k = f.rfind('/');
+        if (k != std::string::npos) dir = f.substr(0, k);
+    }
+    std::string path = dir + "/libsprl_amd_torch.so";
+    void* lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(SPRL_E_MODEL, std::string("cannot load LibTorch evaluator plugin: ") + dlerror());
+    e->torch.lib = lib;
+    e->torch.load = (void* (*)(const char*, int, char*, int))dlsym(lib, "sprl_torch_load");
+    e->torch.forward = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, char*, int))dlsym(lib, "sprl_torch_forward");
+    e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
+    if (!e->torch.load || !e->torch.forward || !e->torch.release)
+        return fail(SPRL_E_MODEL, "LibTorch evaluator plugin lacks required symbols");
+    return 0;
+}
+
+int check_device_error(sprl_engine* e, const Counters& c) {
+    if (c.error == ERR_NONE) return 0;
+    char buf[256];
+    const char* what = c.error == ERR_ARENA_FULL ? "node arena full even after compaction (raise node_cap)"
+                       : c.error == ERR_NO_SPARE ? "no spare arena free for compaction (raise spare_arenas)"
+                       : c.error == ERR_MAX_PLIES ? "game longer than max_plies"
+                                                  : "search line deeper than the path buffer";
+    snprintf(buf, sizeof(buf), "game %u: %s", c.error_game, what);
+    e->running = false;
+    return fail((c.error == ERR_ARENA_FULL || c.error == ERR_NO_SPARE) ? SPRL_E_NODEPOOL : SPRL_E_LIMIT, buf);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sprl_last_error(void) { return g_last_error.c_str(); }
+
+int sprl_device_available(void) {
+    std::string why;
+    return be::available(&why) ? 1 : 0;
+}
+
+int sprl_config_default(int32_t game, sprl_config* cfg) {
+    if (!cfg || (game != SPRL_OTHELLO && game != SPRL_CONNECT_FOUR)) return fail(SPRL_E_CONFIG, "unknown game");
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->game = game;
+    cfg->device = 0;
+    cfg->concurrent_games = 4096;
+    cfg->num_traversals = 800;
+    cfg->max_batch = 8;                                   // OTHWorker.cpp:24, C4Worker.cpp:23
+    cfg->max_queue = 4;                                   // OTHWorker.cpp:25, C4Worker.cpp:24
+    cfg->dir_eps = 0.25f;                                 // OTHWorker.cpp:27, C4Worker.cpp:26
+    cfg->dir_alpha = game == SPRL_OTHELLO ? 0.3f : 0.5f;  // OTHWorker.cpp:28, C4Worker.cpp:27
+    cfg->u_weight = 1.1f;                                 // constants.hpp:6
+    cfg->early_cutoff = 15;                               // constants.hpp:8
+    cfg->early_exp = 0.98f;                               // constants.hpp:9
+    cfg->rest_exp = 10.0f;                                // constants.hpp:10
+    cfg->use_symmetry = 1;
+    cfg->add_noise = 1;
+    cfg->mask_frame = SPRL_MASK_REFERENCE;
+    cfg->seed = 1;
+    cfg->stream_base = 1;
+    return 0;
+}
+
+int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
+    if (!cfg || !out) return fail(SPRL_E_CONFIG, "null argument");
+    *out = nullptr;
+    if (cfg->game != SPRL_OTHELLO && cfg->game != SPRL_CONNECT_FOUR) return fail(SPRL_E_CONFIG, "unknown game");
+    if (cfg->concurrent_games < 1) return fail(SPRL_E_CONFIG, "concurrent_games must be >= 1");
+    if (cfg->num_traversals < 1) return fail(SPRL_E_CONFIG, "num_traversals must be >= 1");
+    if (cfg->max_batch < 1) return fail(SPRL_E_CONFIG, "max_batch must be >= 1");
+    if (cfg->max_queue < 1 || cfg->max_queue > SPRL_MAXQ) return fail(SPRL_E_CONFIG, "max_queue must be in [1, 8]");
+    if (cfg->stream_base < 1) return fail(SPRL_E_CONFIG, "stream_base must be >= 1 (stream 0 means 'pick one' in the reference)");
+    if (cfg->node_cap < 0 || cfg->node_cap > 65535) return fail(SPRL_E_CONFIG, "node_cap must be <= 65535");
+    if (!(cfg->dir_alpha > 0.0f)) return fail(SPRL_E_CONFIG, "dir_alpha must be > 0");
+    std::string err;
+    if (be::init(cfg->device, &err) != 0) return fail(SPRL_E_DEVICE, "no usable gfx950 device: " + err);
+
+    sprl_engine* e = new sprl_engine();
+    e->cfg = *cfg;
+    e->g = geom_of(cfg->game);
+    EngineParams& P = e->P;
+    memset(&P, 0, sizeof(P));
+    P.num_traversals = cfg->num_traversals;
+    P.max_batch = cfg->max_batch;
+    P.max_queue = cfg->max_queue;
+    P.dir_eps = cfg->dir_eps;
+    P.dir_alpha = cfg->dir_alpha;
+    P.u_weight = cfg->u_weight;
+    P.early_cutoff = cfg->early_cutoff;
+    P.early_exp = cfg->early_exp;
+    P.rest_exp = cfg->rest_exp;
+    P.use_sym = cfg->use_symmetry ? 1 : 0;
+    P.add_noise = cfg->add_noise ? 1 : 0;
+    P.eval_kind = EVAL_RANDOM;
+    P.mask_frame = cfg->mask_frame;
+    P.stream_base = cfg->stream_base;
+    P.seed = cfg->seed;
+    P.num_slots = cfg->concurrent_games;
+    P.num_spare = cfg->spare_arenas > 0 ? cfg->spare_arenas : (cfg->concurrent_games / 64 > 8 ? cfg->concurrent_games / 64 : 8);
+    long cap = cfg->node_cap > 0 ? cfg->node_cap : (long)cfg->num_traversals * 52 + 1024;
+    if (cap > 65535) cap = 65535;
+    if (cap < cfg->max_batch + 8) cap = cfg->max_batch + 8;
+    P.node_cap = (int)cap;
+    P.max_plies = cfg->max_plies > 0 ? cfg->max_plies : e->g.default_max_plies;
+    P.max_depth = e->g.max_depth;
+    P.planes = 3;
+    P.rounds = 1;
+
+    const size_t arenas = (size_t)(P.num_slots + P.num_spare);
+    const size_t nq = (size_t)P.num_slots * SPRL_MAXQ;
+    bool ok = true;
+    ok = ok && (P.arenas = (uint8_t*)dev_alloc(e, arenas * (size_t)P.node_cap * SPRL_NODE_BYTES));
+    ok = ok && (P.arena_used = (uint32_t*)dev_alloc(e, arenas * sizeof(uint32_t)));
+    ok = ok && (P.ctl = (GameCtl*)dev_alloc(e, (size_t)P.num_slots * sizeof(GameCtl)));
+    ok = ok && (P.paths = (uint32_t*)dev_alloc(e, nq * (size_t)P.max_depth * sizeof(uint32_t)));
+    ok = ok && (P.nn_in = (float*)dev_alloc(e, nq * 3 * (size_t)e->g.cells * sizeof(float)));
+    ok = ok && (e->nn_logits = (float*)dev_alloc(e, nq * (size_t)e->g.A * sizeof(float)));
+    ok = ok && (e->nn_value = (float*)dev_alloc(e, nq * sizeof(float)));
+    ok = ok && (P.counters = (Counters*)dev_alloc(e, sizeof(Counters)));
+    if (!ok) {
+        std::string m = std::string("device allocation failed (") + be::last_error() + ")";
+        sprl_engine_destroy(e);
+        return fail(SPRL_E_DEVICE, m);
+    }
+    P.nn_logits = e->nn_logits;
+    P.nn_value = e->nn_value;
+    be::dmemset(P.nn_in, 0, nq * 3 * (size_t)e->g.cells * sizeof(float));
+    be::dmemset(e->nn_logits, 0, nq * (size_t)e->g.A * sizeof(float));
+    be::dmemset(e->nn_value, 0, nq * sizeof(float));
+    be::sync();
+    *out = e;
+    return 0;
+}
+
+void sprl_engine_destroy(sprl_engine* e) {
+    if (!e) return;
+    resolve_marks(e);
+    if (e->torch_model && e->torch.release) e->torch.release(e->torch_model);
+    for (void* p : e->allocs) be::dfree(p);
+    delete e;
+}
+
+int sprl_engine_set_model(sprl_engine* e, const char* model) {
+    if (!e || !model) return fail(SPRL_E_CONFIG, "null argument");
+    if (e->running) return fail(SPRL_E_STATE, "cannot change the evaluator while a run is in progress");
+    if (strcmp(model, "random") == 0) {          // GridWorker.hpp:36-38,125-127
+        e->eval_kind = SPRL_EVAL_RANDOM;
+        return 0;
+    }
+    if (strcmp(model, "heuristic") == 0) {
+        if (e->cfg.game != SPRL_OTHELLO) return fail(SPRL_E_CONFIG, "the heuristic evaluator exists for Othello only");
+        e->eval_kind = SPRL_EVAL_HEURISTIC;
+        return 0;
+    }
+    int rc = load_torch_plugin(e);
+    if (rc) return rc;
+    char err[512] = { 0 };
+    void* m = e->torch.load(model, e->cfg.device, err, (int)sizeof(err));
+    if (!m) return fail(SPRL_E_MODEL, std::string("cannot load TorchScript model '") + model + "': " + err);
+    if (e->torch_model) e->torch.release(e->torch_model);
+    e->torch_model = m;
+    e->forward_cb = nullptr;
+    e->eval_kind = SPRL_EVAL_NETWORK;
+    return 0;
+}
+
+int sprl_engine_set_forward(sprl_engine* e, sprl_forward_fn fn, void* user) {
+    if (!e || !fn) return fail(SPRL_E_CONFIG, "null argument");
+    if (e->running) return fail(SPRL_E_STATE, "cannot change the evaluator while a run is in progress");
+    e->forward_cb = fn;
+    e->forward_user = user;
+    e->eval_kind = SPRL_EVAL_NETWORK;
+    return 0;
+}
+
+int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
+    if (!e) return fail(SPRL_E_CONFIG, "null engine");
+    if (num_games < 1) return fail(SPRL_E_CONFIG, "num_games must be >= 1");
+    EngineParams& P = e->P;
+    // (re)allocate record buffers for this run
+    const size_t np = (size_t)num_games * (size_t)P.max_plies;
+    if (num_games > e->num_games || !P.rec_boards) {
+        // earlier record buffers stay in `allocs` and are released at destroy; runs normally reuse the size
+        bool ok = true;
+        ok = ok && (P.rec_boards = (uint64_t*)dev_alloc(e, np * 2 * sizeof(uint64_t)));
+        ok = ok && (P.rec_movers = (uint8_t*)dev_alloc(e, np));
+        ok = ok && (P.rec_pdf = (float*)dev_alloc(e, np * (size_t)e->g.A * sizeof(float)));
+        ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
+        ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
+        if (!ok) return fail(SPRL_E_DEVICE, std::string("record allocation failed (") + be::last_error() + ")");
+    }
+    e->num_games = num_games;
+    P.num_games = num_games;
+    P.eval_kind = e->eval_kind;
+    std::vector<GameCtl> ctl((size_t)P.num_slots);
+    memset(ctl.data(), 0, ctl.size() * sizeof(GameCtl));
+    for (int s = 0; s < P.num_slots; ++s) {
+        ctl[(size_t)s].status = ST_FRESH;
+        ctl[(size_t)s].arena = (uint32_t)s;
+    }
+    std::vector<uint32_t> used((size_t)(P.num_slots + P.num_spare), 0u);
+    for (int s = 0; s < P.num_slots; ++s) used[(size_t)s] = 1u;
+    Counters c;
+    memset(&c, 0, sizeof(c));
+    int rc = 0;
+    rc |= be::h2d(P.ctl, ctl.data(), ctl.size() * sizeof(GameCtl));
+    rc |= be::h2d(P.arena_used, used.data(), used.size() * sizeof(uint32_t));
+    rc |= be::h2d(P.counters, &c, sizeof(c));
+    rc |= be::dmemset(P.rec_nplies, 0, (size_t)num_games * sizeof(int32_t));
+    rc |= be::dmemset(P.rec_pdf, 0, np * (size_t)e->g.A * sizeof(float));
+    rc |= be::sync();
+    if (rc) return fail(SPRL_E_DEVICE, be::last_error());
+    e->running = true;
+    return 0;
+}
+
+int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_t* active_slots) {
+    if (!e) return fail(SPRL_E_CONFIG, "null engine");
+    if (!e->running) return fail(SPRL_E_STATE, "sprl_engine_begin has not been called");
+    if (rounds < 1) rounds = 1;
+    EngineParams& P = e->P;
+    auto t0 = std::chrono::steady_clock::now();
+    const bool net = e->eval_kind == SPRL_EVAL_NETWORK;
+    const int launches = net ? rounds : 1;
+    P.rounds = net ? 1 : rounds;
+    const int batch = P.num_slots * SPRL_MAXQ;
+    for (int r = 0; r < launches; ++r) {
+        be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
+        void* k0 = e->cfg.profile ? be::mark() : nullptr;
+        if (be::launch_step(e->cfg.game, P) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+        if (e->cfg.profile) {
+            e->marks.push_back(k0);
+            e->marks.push_back(be::mark());
+            e->mark_kind.push_back(0);
+        }
+        e->launches++;
+        if (net) {
+            void* n0 = e->cfg.profile ? be::mark() : nullptr;
+            int rc;
+            char err[512] = { 0 };
+            if (e->forward_cb) {
+                rc = e->forward_cb(e->forward_user, P.nn_in, batch, e->nn_logits, e->nn_value);
+                if (rc) snprintf(err, sizeof(err), "forward callback returned %d", rc);
+            } else {
+                rc = e->torch.forward(e->torch_model, P.nn_in, batch, 3, e->g.rows, e->g.cols, e->nn_logits,
+                                      e->g.A, e->nn_value, err, (int)sizeof(err));
+            }
+            if (rc) {
+                e->running = false;
+                return fail(SPRL_E_MODEL, std::string("network forward failed: ") + err);
+            }
+            if (e->cfg.profile) {
+                e->marks.push_back(n0);
+                e->marks.push_back(be::mark());
+                e->mark_kind.push_back(1);
+            }
+            e->nn_batches++;
+        }
+        if (e->marks.size() >= 4096) resolve_marks(e);
+    }
+    e->rounds += rounds;
+    Counters c;
+    if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+    e->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (games_done) *games_done = (int32_t)c.games_done;
+    if (active_slots) *active_slots = (int32_t)c.active_slots;
+    return check_device_error(e, c);
+}
+
+int sprl_engine_collect(sprl_engine* e, sprl_records* out) {
+    if (!e || !out) return fail(SPRL_E_CONFIG, "null argument");
+    if (!e->running) return fail(SPRL_E_STATE, "no run in progress");
+    EngineParams& P = e->P;
+    const Geom& g = e->g;
+    const int ng = e->num_games;
+    const size_t np = (size_t)ng * (size_t)P.max_plies;
+    std::vector<int32_t> nplies((size_t)ng);
+    std::vector<int8_t> winners((size_t)ng);
+    std::vector<uint64_t> boards(np * 2);
+    std::vector<uint8_t> movers(np);
+    std::vector<float> pdfs(np * (size_t)g.A);
+    int rc = be::sync();
+    rc |= be::d2h(nplies.data(), P.rec_nplies, nplies.size() * sizeof(int32_t));
+    rc |= be::d2h(winners.data(), P.rec_winner, winners.size());
+    rc |= be::d2h(boards.data(), P.rec_boards, boards.size() * sizeof(uint64_t));
+    rc |= be::d2h(movers.data(), P.rec_movers, movers.size());
+    rc |= be::d2h(pdfs.data(), P.rec_pdf, pdfs.size() * sizeof(float));
+    if (rc) return fail(SPRL_E_DEVICE, be::last_error());
+    RecordsOwner* o = new RecordsOwner();
+    o->ply_offset.resize((size_t)ng + 1);
+    int64_t total = 0;
+    for (int i = 0; i < ng; ++i) {
+        o->ply_offset[(size_t)i] = (int32_t)total;
+        if (nplies[(size_t)i] <= 0) {
+            delete o;
+            return fail(SPRL_E_STATE, "collect called before every game has finished");
+        }
+        total += nplies[(size_t)i];
+    }
+    o->ply_offset[(size_t)ng] = (int32_t)total;
+    o->boards.resize((size_t)total * (size_t)g.cells);
+    o->movers.resize((size_t)total);
+    o->pdfs.resize((size_t)total * (size_t)g.A);
+    o->winners = winners;
+    for (int i = 0; i < ng; ++i) {
+        for (int p = 0; p < nplies[(size_t)i]; ++p) {
+            const size_t src = (size_t)i * (size_t)P.max_plies + (size_t)p;
+            const size_t dst = (size_t)o->ply_offset[(size_t)i] + (size_t)p;
+            const uint64_t p0 = boards[src * 2], p1 = boards[src * 2 + 1];
+            int8_t* b = &o->boards[dst * (size_t)g.cells];
+            for (int c = 0; c < g.cells; ++c) b[c] = ((p0 >> c) & 1) ? 0 : (((p1 >> c) & 1) ? 1 : -1);
+            o->movers[dst] = (int8_t)movers[src];
+            memcpy(&o->pdfs[dst * (size_t)g.A], &pdfs[src * (size_t)g.A], (size_t)g.A * sizeof(float));
+        }
+    }
+    memset(out, 0, sizeof(*out));
+    out->game = e->cfg.game;
+    out->num_games = ng;
+    out->rows = g.rows;
+    out->cols = g.cols;
+    out->cells = g.cells;
+    out->actions = g.A;
+    out->nsym = g.nsym;
+    out->use_symmetry = e->cfg.use_symmetry ? 1 : 0;
+    out->total_plies = total;
+    out->ply_offset = o->ply_offset.data();
+    out->boards = o->boards.data();
+    out->movers = o->movers.data();
+    out->pdfs = o->pdfs.data();
+    out->winners = o->winners.data();
+    out->owner_ = o;
+    e->running = false;
+    return 0;
+}
+
+int sprl_engine_run(sprl_engine* e, int32_t num_games, sprl_records* out) {
+    int rc = sprl_engine_begin(e, num_games);
+    if (rc) return rc;
+    int32_t done = 0, active = 0;
+    const int chunk = e->eval_kind == SPRL_EVAL_NETWORK ? 32 : 64;
+    do {
+        rc = sprl_engine_step(e, chunk, &done, &active);
+        if (rc) return rc;
+    } while (done < num_games);
+    return sprl_engine_collect(e, out);
+}
+
+void sprl_records_free(sprl_records* r) {
+    if (!r || !r->owner_) return;
+    delete (RecordsOwner*)r->owner_;
+    memset(r, 0, sizeof(*r));
+}
+
+int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
+    if (!e || !out) return fail(SPRL_E_CONFIG, "null argument");
+    memset(out, 0, sizeof(*out));
+    resolve_marks(e);
+    std::vector<GameCtl> ctl((size_t)e->P.num_slots);
+    if (be::sync() != 0 || be::d2h(ctl.data(), e->P.ctl, ctl.size() * sizeof(GameCtl)) != 0)
+        return fail(SPRL_E_DEVICE, be::last_error());
+    for (const GameCtl& c : ctl) {
+        out->games += (int64_t)c.stats.games;
+        out->plies += (int64_t)c.stats.plies;
+        out->traversals += (int64_t)c.stats.traversals;
+        out->levels += (int64_t)c.stats.levels;
+        out->expansions += (int64_t)c.stats.expansions;
+        out->nn_evals += (int64_t)c.stats.nn_evals;
+        out->terminal_hits += (int64_t)c.stats.terminal_hits;
+        out->gray_hits += (int64_t)c.stats.gray_hits;
+        out->dup_hits += (int64_t)c.stats.dup_hits;
+        out->nodes_created += (int64_t)c.stats.nodes_created;
+        out->compactions += (int64_t)c.stats.compactions;
+        if ((int64_t)c.stats.max_alloc > out->max_nodes_in_arena) out->max_nodes_in_arena = (int64_t)c.stats.max_alloc;
+    }
+    out->rounds = e->rounds;
+    out->kernel_launches = e->launches;
+    out->nn_batches = e->nn_batches;
+    out->seconds_total = e->seconds;
+    out->kernel_ms = e->kernel_ms;
+    out->nn_ms = e->nn_ms;
+    out->hbm_bytes = (int64_t)e->hbm_bytes;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// records -> training samples (SelfPlay.hpp:86-92,127-133,151-189; GridWorker.hpp:146-171)
+// ---------------------------------------------------------------------------------------------------------
+int64_t sprl_records_num_samples(const sprl_records* r) {
+    if (!r) return 0;
+    return r->total_plies * (r->use_symmetry ? r->nsym : 1);
+}
+
+int sprl_records_expand_boards(const sprl_records* r, int8_t* boards, int8_t* players) {
+    if (!r || !boards || !players) return fail(SPRL_E_CONFIG, "null argument");
+    const int ns = r->use_symmetry ? r->nsym : 1;
+    for (int64_t p = 0; p < r->total_plies; ++p)
+        for (int s = 0; s < ns; ++s) {
+            int8_t* out = boards + (size_t)(p * ns + s) * (size_t)r->cells;
+            const int8_t* in = r->boards + (size_t)p * (size_t)r->cells;
+            for (int c = 0; c < r->cells; ++c) out[map_cell(r->game, s, c)] = in[c];
+            players[p * ns + s] = r->movers[p];
+        }
+    return 0;
+}
+
+int sprl_records_expand(const sprl_records* r, float* states, float* distributions, float* outcomes) {
+    if (!r || !states || !distributions || !outcomes) return fail(SPRL_E_CONFIG, "null argument");
+    const int ns = r->use_symmetry ? r->nsym : 1;
+    const int cells = r->cells, A = r->actions;
+    for (int gi = 0; gi < r->num_games; ++gi) {
+        const int8_t w = r->winners[gi];
+        for (int p = r->ply_offset[gi]; p < r->ply_offset[gi + 1]; ++p) {
+            const int8_t mover = r->movers[p];
+            const int8_t* in = r->boards + (size_t)p * (size_t)cells;
+            const float* pdf = r->pdfs + (size_t)p * (size_t)A;
+            const float reward = w < 0 ? 0.0f : (w == mover ? 1.0f : -1.0f);   // OthelloNode.cpp:94-100
+            for (int s = 0; s < ns; ++s) {
+                const size_t n = (size_t)p * (size_t)ns + (size_t)s;
+                float* st = states + n * 3 * (size_t)cells;
+                float* di = distributions + n * (size_t)A;
+                for (int c = 0; c < cells; ++c) {
+                    const int t = map_cell(r->game, s, c);
+                    st[t] = in[c] == mover ? 1.0f : 0.0f;                       // own plane
+                    st[cells + t] = (in[c] >= 0 && in[c] != mover) ? 1.0f : 0.0f;  // opponent plane
+                    st[2 * cells + t] = mover == 0 ? 1.0f : 0.0f;               // colour plane
+                }
+                for (int a = 0; a < A; ++a) di[map_action(r->game, s, a)] = pdf[a];
+                outcomes[n] = reward;
+            }
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// .npy v1.0 writer with the reference's exact header bytes (utils/npy.hpp:430-476)
+// ---------------------------------------------------------------------------------------------------------
+static int write_npy_f32(const std::string& path, const float* data, const std::vector<uint64_t>& shape) {
+    std::string tuple;
+    char num[32];
+    if (shape.size() == 1) {
+        snprintf(num, sizeof(num), "(%llu,)", (unsigned long long)shape[0]);
+        tuple = num;
+    } else {
+        tuple = "(";
+        for (size_t i = 0; i < shape.size(); ++i) {
+            snprintf(num, sizeof(num), "%llu", (unsigned long long)shape[i]);
+            tuple += num;
+            tuple += i + 1 < shape.size() ? ", " : ")";
+        }
+    }
+    std::string dict = "{'descr': '<f4', 'fortran_order': False, 'shape': " + tuple + ", }";
+    size_t length = 6 + 2 + 2 + dict.size() + 1;
+    size_t pad = 16 - length % 16;
+    size_t count = 1;
+    for (uint64_t s : shape) count *= (size_t)s;
+    std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return -1;
+    const unsigned char magic[8] = { 0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0 };
+    uint16_t hl = (uint16_t)(dict.size() + pad + 1);
+    unsigned char le[2] = { (unsigned char)(hl & 0xff), (unsigned char)(hl >> 8) };
+    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(le, 1, 2, f) == 2 && fwrite(dict.data(), 1, dict.size(), f) == dict.size();
+    for (size_t i = 0; ok && i < pad; ++i) ok = fputc(' ', f) != EOF;
+    ok = ok && fputc('\n', f) != EOF;
+    ok = ok && fwrite(data, sizeof(float), count, f) == count;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        remove(tmp.c_str());
+        return -1;
+    }
+    return rename(tmp.c_str(), path.c_str());
+}
+
+int sprl_write_npy(const char* path_prefix, const sprl_records* r) {
+    if (!path_prefix || !r) return fail(SPRL_E_CONFIG, "null argument");
+    const int64_t n = sprl_records_num_samples(r);
+    std::vector<float> states((size_t)n * 3 * (size_t)r->cells), dists((size_t)n * (size_t)r->actions), outs((size_t)n);
+    int rc = sprl_records_expand(r, states.data(), dists.data(), outs.data());
+    if (rc) return rc;
+    std::string p(path_prefix);
+    // controller polls for all three files (scripts/othello_controller.py:83-93): outcomes goes last, each
+    // file appears atomically
+    if (write_npy_f32(p + "_states.npy", states.data(), { (uint64_t)n, 3, (uint64_t)r->rows, (uint64_t)r->cols }) != 0 ||
+        write_npy_f32(p + "_distributions.npy", dists.data(), { (uint64_t)n, (uint64_t)r->actions }) != 0 ||
+        write_npy_f32(p + "_outcomes.npy", outs.data(), { (uint64_t)n }) != 0)
+        return fail(SPRL_E_IO, "io error: failed to open a file.");
+    return 0;
+}
+
+}  // extern "C"

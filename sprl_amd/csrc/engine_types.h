@@ -1,0 +1,111 @@
+// engine_types.h — device data layout of the self-play engine (shared by host and kernels).
+//
+// HBM layout (sized for 288 GB; numbers for Othello, 4096 concurrent games, 800 traversals/move):
+//   arenas   [slots + spare][node_cap] x 1 KiB nodes — one bump arena per game, no per-move compaction:
+//            re-rooting (UCTTree::advanceDecision, uct/UCTTree.hpp:197-210) is O(1) by bumping the game's
+//            epoch, which lazily turns every active node gray (clearSubtree :283-298); pruned siblings are
+//            simply never reached again.  ~33 k nodes are created per game, so node_cap = 45056 -> 44 MiB
+//            per game, 176 GiB for 4096 games.  If an arena fills, the live subtree is Cheney-copied into a
+//            spare arena (rare; exercised by tests with tiny caps).
+//   node     1 KiB: rows N[64] W[64] P[64] f32 (lane a <-> action a: one coalesced 256 B access per row),
+//            child[64] u16, 64 B header (bitboards, legal mask, cached value, pass-edge stats, flags).
+//            The cached network policy lives in the P row (it is only ever consumed through expand()).
+//   paths    [slots][MAXQ][MAX_DEPTH] u32 (node<<8 | action) for leaves waiting on the network.
+//   nn_in    [slots*MAXQ][2H+1][R][C] f32, nn_logits [slots*MAXQ][A], nn_value [slots*MAXQ]
+//   records  compact per ply: 2 x u64 bitboards, mover, tempered pdf f32[A]; winner per game.
+#ifndef SPRL_ENGINE_TYPES_H
+#define SPRL_ENGINE_TYPES_H
+
+#include <stdint.h>
+
+#define SPRL_NODE_BYTES 1024
+#define SPRL_ROW 64
+#define SPRL_NONE16 0xFFFFu
+#define SPRL_MAXQ 8
+#define SPRL_PASS 64
+
+enum { F_EVAL = 1, F_TERMINAL = 2, F_PASS = 4 };
+enum { ST_IDLE = 0, ST_ACTIVE = 1, ST_ERROR = 2, ST_FRESH = 3 };
+enum { EVAL_RANDOM = 0, EVAL_HEURISTIC = 1, EVAL_NETWORK = 2 };
+enum { MASK_REFERENCE = 0, MASK_SYMMETRISED = 1 };
+enum {
+    ERR_NONE = 0,
+    ERR_ARENA_FULL = 1,     // live subtree does not fit the arena even after compaction
+    ERR_NO_SPARE = 2,       // no spare arena free for compaction
+    ERR_MAX_PLIES = 3,      // game longer than the record capacity
+    ERR_MAX_DEPTH = 4,      // search line longer than the path capacity
+};
+
+struct NodeHdr {            // 64 bytes at node + 896
+    uint64_t p0, p1;        // stones of Player::ZERO / Player::ONE
+    uint64_t legal;         // legal lane-actions of the side to move
+    float value;            // cached network value (UCTNode::m_networkValue)
+    uint32_t exp_epoch;     // node is active iff exp_epoch == game epoch (UCTNode::m_isExpanded)
+    float passN, passW, passP;
+    uint32_t passChild;
+    uint8_t player, flags;
+    int8_t winner;
+    uint8_t pad0;
+    uint16_t action, pad1;
+    uint32_t pad2[2];
+};
+
+struct GameStats {
+    unsigned long long traversals, levels, expansions, nn_evals, terminal_hits, gray_hits, dup_hits,
+        nodes_created, compactions, games, plies, max_alloc;
+};
+
+struct GameCtl {
+    uint64_t rng_state, rng_inc;
+    uint32_t status;
+    uint32_t game_id;
+    uint32_t arena;         // arena index in the pool
+    uint32_t root;          // decision node
+    uint32_t n_alloc;
+    uint32_t epoch;         // ply + 1
+    float rootN, rootW;     // decision node's own N()/W() (lives in its parent's row in the reference, Q6)
+    int32_t ply;
+    int32_t traversals;
+    int32_t n_leaves;
+    uint32_t root_player;
+    uint32_t leaf_node[SPRL_MAXQ];
+    uint32_t leaf_depth[SPRL_MAXQ];
+    uint32_t leaf_sym[SPRL_MAXQ];
+    GameStats stats;
+};
+
+struct Counters {
+    uint32_t next_game;     // next global game index to start
+    uint32_t games_done;
+    uint32_t error;         // first ERR_* raised by any game
+    uint32_t error_game;
+    uint32_t active_slots;  // slots still holding an unfinished game after the last step
+    uint32_t pad[3];
+};
+
+struct EngineParams {
+    int32_t num_traversals, max_batch, max_queue;
+    float dir_eps, dir_alpha, u_weight;
+    int32_t early_cutoff;
+    float early_exp, rest_exp;
+    int32_t use_sym, add_noise, eval_kind, mask_frame;
+    int32_t stream_base;
+    uint64_t seed;
+    int32_t node_cap, num_slots, num_spare, num_games, max_plies, rounds;
+    int32_t max_depth, planes;
+    uint8_t* arenas;
+    uint32_t* arena_used;   // [num_slots + num_spare] 0 free / 1 used
+    GameCtl* ctl;
+    uint32_t* paths;
+    float* nn_in;
+    const float* nn_logits;
+    const float* nn_value;
+    uint64_t* rec_boards;
+    uint8_t* rec_movers;
+    float* rec_pdf;
+    int32_t* rec_nplies;
+    int8_t* rec_winner;
+    Counters* counters;
+};
+
+#endif  // SPRL_ENGINE_TYPES_H

@@ -1,0 +1,638 @@
+// step_kernel.h — the self-play hot path: one 64-lane wavefront owns one game and its UCT tree.
+//
+// One call of step_game<G>() advances one game slot by up to `rounds` search rounds.  A round is the
+// reference's inner loop body (selfplay/SelfPlay.hpp:100-108):
+//     finish   = UCTTree::evaluateAndBackpropLeaves  (uct/UCTTree.hpp:124-184)  for the leaves queued last round
+//     move     = visits -> tempered pdf -> sample -> re-root  (SelfPlay.hpp:111-148) once >= numTraversals
+//     select   = UCTTree::searchAndGetLeaves          (uct/UCTTree.hpp:76-114) : <= maxBatch traversals,
+//                terminal / gray leaves backed up immediately, empty leaves queued (<= maxQueue)
+// With the in-kernel evaluators (RandomNetwork / OthelloHeuristic) rounds chain inside one launch; with the
+// network evaluator a launch ends after `select` has written the symmetrised input planes of the queued leaves,
+// LibTorch-ROCm runs the CNN on the dense batch, and the next launch starts with `finish`.
+//
+// Lane mapping: lane a <-> action a (Othello: cell a; pass is a scalar edge in the node header).  Per level
+// of a descent each lane loads N[a], W[a], P[a], child[a] (4 coalesced rows), the PUCT score is computed per
+// lane with IEEE fp32 ops in the reference's order (UCTNode.hpp:200,210,236; no FMA contraction), the arg-max
+// is a wave butterfly, the tie set is a ballot, and the tie is broken with the reference's UniformInt draw.
+//
+// Coherence rule used throughout: an address is always written by the lane(s) that later read it (row element
+// a by lane a, header fields by all lanes with a uniform value), so intra-wave RAW through global memory
+// is always same-lane program order; the one exception (arena compaction) is followed by a fence.
+#ifndef SPRL_STEP_KERNEL_H
+#define SPRL_STEP_KERNEL_H
+
+#include "dev_rng.h"
+#include "engine_types.h"
+#include "games.h"
+#include "wave.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace sprl {
+
+SPRL_DEV uint8_t* node_at(uint8_t* abase, uint32_t idx) { return abase + (size_t)idx * SPRL_NODE_BYTES; }
+SPRL_DEV float* rowN(uint8_t* n) { return (float*)n; }
+SPRL_DEV float* rowW(uint8_t* n) { return (float*)(n + 256); }
+SPRL_DEV float* rowP(uint8_t* n) { return (float*)(n + 512); }
+SPRL_DEV uint16_t* rowC(uint8_t* n) { return (uint16_t*)(n + 768); }
+SPRL_DEV NodeHdr* hdr_of(uint8_t* n) { return (NodeHdr*)(n + 896); }
+// wave-uniform copy of a node header; every lane has loaded it before any lane may go on to modify it
+SPRL_DEV NodeHdr load_hdr(uint8_t* n) {
+    NodeHdr h = *hdr_of(n);
+    wv::sync();
+    return h;
+}
+
+struct Game {                 // per-wave working state (wave-uniform values)
+    Pcg32 rng;
+    uint8_t* abase;
+    uint32_t arena, root, n_alloc, epoch, root_player, game_id, status;
+    float rootN, rootW;
+    int ply, traversals, n_leaves;
+    GameStats st;
+};
+
+SPRL_DEV void raise_error(const EngineParams& P, Game& g, uint32_t code) {
+    if (wv::lane() == 0) {
+        if (wv::atomic_cas_u32(&P.counters->error, 0u, code) == 0u) P.counters->error_game = g.game_id;
+    }
+    g.status = ST_ERROR;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// node creation (UCTNode::getAddChild -> GameNode::getAddChild -> getNextNodeImpl)
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void write_new_node(uint8_t* np, const Pos& s, int action) {
+    NodeHdr* h = hdr_of(np);
+    h->p0 = s.p0;
+    h->p1 = s.p1;
+    h->legal = s.legal;
+    h->value = 0.0f;
+    h->exp_epoch = 0;
+    h->passN = 0.0f;
+    h->passW = 0.0f;
+    h->passP = 0.0f;
+    h->passChild = SPRL_NONE16;
+    h->player = s.player;
+    h->flags = (uint8_t)((s.terminal ? F_TERMINAL : 0) | (s.pass_legal ? F_PASS : 0));
+    h->winner = s.winner;
+    h->action = (uint16_t)action;
+    rowC(np)[wv::lane()] = SPRL_NONE16;
+}
+
+SPRL_DEV Pos pos_of(const NodeHdr& h) {
+    Pos s;
+    s.p0 = h.p0;
+    s.p1 = h.p1;
+    s.legal = h.legal;
+    s.player = h.player;
+    s.pass_legal = (h.flags & F_PASS) ? 1 : 0;
+    s.terminal = (h.flags & F_TERMINAL) ? 1 : 0;
+    s.winner = h.winner;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// expand (UCTNode::expand, uct/UCTNode.hpp:312-348).  The P row already holds the cached, legal-masked
+// network policy; N and W rows are (re)initialised here, which is what EdgeStatistics::reset() left behind.
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void expand_node(const EngineParams& P, Game& g, uint8_t* np, const NodeHdr& hc, bool add_noise) {
+    const int l = wv::lane();
+    NodeHdr* h = hdr_of(np);
+    const uint64_t legal = hc.legal;
+    const bool pass_legal = G::HAS_PASS && (hc.flags & F_PASS);
+    rowN(np)[l] = 0.0f;
+    rowW(np)[l] = 0.0f;
+    h->passN = 0.0f;
+    h->passW = 0.0f;
+    h->exp_epoch = g.epoch;
+    if (add_noise) {
+        const int num_legal = wv::popc64(legal) + (pass_legal ? 1 : 0);
+        const bool mine = (legal >> l) & 1ull;
+        const int my_rank = wv::popc64(legal & wv::lt_mask(l));
+        NormalState ns = { 0.0f, 0 };
+        float my_noise = 0.0f, pass_noise = 0.0f, sum = 0.0f;
+        for (int i = 0; i < num_legal; ++i) {                 // Random::Dirichlet, utils/random.cpp:61-74
+            float s = rng_gamma(g.rng, ns, P.dir_alpha);
+            sum += s;
+            if (mine && my_rank == i) my_noise = s;
+            if (i == num_legal - 1 && pass_legal) pass_noise = s;
+        }
+        const float norm = 1.0f / sum;
+        my_noise *= norm;
+        pass_noise *= norm;
+        const double keep = 1.0 - (double)P.dir_eps;          // UCTNode.hpp:341-343 (double arithmetic)
+        if (mine) {
+            float p = rowP(np)[l];
+            rowP(np)[l] = (float)(keep * (double)p + (double)(P.dir_eps * my_noise));
+        }
+        if (pass_legal) h->passP = (float)(keep * (double)hc.passP + (double)(P.dir_eps * pass_noise));
+    }
+    g.st.expansions++;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backup (UCTTree::backup, uct/UCTTree.hpp:261-273) over a stored path of `depth` edges
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void backup_path(Game& g, uint32_t my_entry0, uint32_t my_entry1, int depth, int leaf_player, float value) {
+    const int l = wv::lane();
+    const float est = -value * (leaf_player == 0 ? 1.0f : -1.0f);
+    g.rootW += 1.0f + est * (g.root_player == 0 ? 1.0f : -1.0f);
+    for (int j = 0; j < depth; ++j) {
+        uint32_t e = j < 64 ? wv::bcast_u32(my_entry0, j) : wv::bcast_u32(my_entry1, j - 64);
+        uint32_t node = e >> 8;
+        int a = (int)(e & 0xffu);
+        int child_player = (int)(g.root_player ^ ((uint32_t)(j + 1) & 1u));
+        float add = 1.0f + est * (child_player == 0 ? 1.0f : -1.0f);
+        uint8_t* np = node_at(g.abase, node);
+        if (G::HAS_PASS && a == SPRL_PASS) {
+            NodeHdr* h = hdr_of(np);
+            const float w = h->passW;
+            wv::sync();
+            h->passW = w + add;
+        } else if (l == a) {
+            rowW(np)[l] = rowW(np)[l] + add;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// evaluators: produce the cached policy (into the P row / passP, masked by legality) and value of a leaf
+// (UCTTree.hpp:136-175 + networks/{RandomNetwork,OthelloHeuristic,GridNetwork}).  `sym` is the symmetry the
+// state was presented in; the mask is deliberately NOT symmetrised in MASK_REFERENCE mode.
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void evaluate_leaf(const EngineParams& P, Game& g, uint8_t* np, NodeHdr& hc, int sym, int nn_slot) {
+    const int l = wv::lane();
+    NodeHdr* h = hdr_of(np);
+    const uint64_t legal = hc.legal;
+    const bool pass_legal = G::HAS_PASS && (hc.flags & F_PASS);
+    // mask as the evaluator sees it, indexed in the symmetrised frame
+    uint64_t used;
+    if (P.mask_frame == MASK_SYMMETRISED && sym != 0) {
+        const int src = l < G::NA ? G::map_action(G::inverse_sym(sym), l) : 0;
+        used = wv::ballot(l < G::NA && ((legal >> src) & 1ull));
+    } else {
+        used = legal;
+    }
+    const bool mine = l < G::NA && ((used >> l) & 1ull);
+    const int num_legal = wv::popc64(used) + (pass_legal ? 1 : 0);
+    float pol, pass_pol = 0.0f, value = 0.0f;
+    if (P.eval_kind == EVAL_NETWORK) {
+        const float* logits = P.nn_logits + (size_t)nn_slot * G::A;
+        float e = mine ? sprl_expf(logits[l]) : 0.0f;                       // GridNetwork.hpp:110-121
+        float e_pass = pass_legal ? sprl_expf(logits[G::A - 1]) : 0.0f;
+        float sum = 0.0f;                                                   // GameActionDist::sum, index order
+        for (uint64_t m = used; m; m &= m - 1) sum += wv::bcast_f32(e, wv::ctz64(m));
+        if (pass_legal) sum += e_pass;
+        if (sum == 0.0f) {
+            float uniform = 1.0f / (float)num_legal;                        // GridNetwork.hpp:124-129
+            pol = mine ? uniform : 0.0f;
+            pass_pol = pass_legal ? uniform : 0.0f;
+        } else {
+            float inv = 1.0f / sum;                                         // GameActionDist.hpp:284-289
+            pol = e * inv;
+            pass_pol = e_pass * inv;
+        }
+        value = P.nn_value[nn_slot];
+    } else {
+        float uniform = 1.0f / (float)num_legal;                            // RandomNetwork.hpp:29-43
+        pol = mine ? uniform : 0.0f;
+        pass_pol = pass_legal ? uniform : 0.0f;
+        if (P.eval_kind == EVAL_HEURISTIC && G::ID == SPRL_GAME_OTHELLO) {  // OthelloHeuristic.cpp:28-49
+            uint64_t own = hc.player ? hc.p1 : hc.p0, opp = hc.player ? hc.p0 : hc.p1;
+            int num_opp = wv::popc64(Othello::legal_moves(opp, own));
+            int num_empty = 64 - wv::popc64(own | opp);
+            value = (float)(num_legal - num_opp) / (float)num_empty;
+        }
+    }
+    // undo the symmetry: policy_orig[a] = policy_sym[map_s(a)] (UCTTree.hpp:162-164)
+    const int from = l < G::NA ? G::map_action(sym, l) : 0;
+    float pol_orig = wv::shfl_f32(pol, from);
+    const bool legal_here = l < G::NA && ((legal >> l) & 1ull);
+    rowP(np)[l] = legal_here ? pol_orig : 0.0f;                             // UCTNode.hpp:320-327
+    hc.passP = pass_legal ? pass_pol : 0.0f;
+    hc.value = value;
+    hc.flags = (uint8_t)(hc.flags | F_EVAL);
+    h->passP = hc.passP;
+    h->value = hc.value;
+    h->flags = hc.flags;
+}
+
+// symmetrised input planes of a queued leaf (GridNetwork.hpp:72-97 after D4GridSymmetrizer.hpp:52-75)
+template <class G>
+SPRL_DEV void encode_leaf(const EngineParams& P, const NodeHdr& h, int sym, int nn_slot) {
+    const int l = wv::lane();
+    if (l < G::CELLS) {
+        const int src = G::map_cell(G::inverse_sym(sym), l);      // out[map_s(i)] = in[i]
+        const uint64_t own = h.player ? h.p1 : h.p0, opp = h.player ? h.p0 : h.p1;
+        float* out = P.nn_in + (size_t)nn_slot * (3 * G::CELLS);
+        out[l] = (float)((own >> src) & 1ull);
+        out[G::CELLS + l] = (float)((opp >> src) & 1ull);
+        out[2 * G::CELLS + l] = h.player == 0 ? 1.0f : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finish: UCTTree::evaluateAndBackpropLeaves for the leaves queued by the previous select
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void finish_leaves(const EngineParams& P, Game& g, int slot, GameCtl* ctl) {
+    const int l = wv::lane();
+    for (int q = 0; q < g.n_leaves; ++q) {
+        const uint32_t leaf = ctl->leaf_node[q];
+        const int depth = (int)ctl->leaf_depth[q];
+        const int sym = (int)ctl->leaf_sym[q];
+        uint8_t* np = node_at(g.abase, leaf);
+        NodeHdr h = load_hdr(np);
+        if (!(h.flags & F_EVAL)) {
+            evaluate_leaf<G>(P, g, np, h, sym, slot * SPRL_MAXQ + q);
+        } else {
+            g.st.dup_hits++;
+        }
+        if (h.exp_epoch != g.epoch) expand_node<G>(P, g, np, h, P.add_noise && leaf == g.root);
+        const uint32_t* path = P.paths + ((size_t)slot * SPRL_MAXQ + q) * P.max_depth;
+        uint32_t e0 = l < depth ? path[l] : 0u;
+        uint32_t e1 = 64 + l < depth ? path[64 + l] : 0u;
+        backup_path<G>(g, e0, e1, depth, h.player, h.value);
+    }
+    g.n_leaves = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// select: UCTTree::searchAndGetLeaves
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ctl, uint32_t* lds_path) {
+    const int l = wv::lane();
+    int trav = 0;
+    while (trav < P.max_batch) {
+        ++trav;
+        // ---- selectLeaf (UCTTree.hpp:225-249) ----
+        uint32_t cur = g.root;
+        float nself = g.rootN;
+        g.rootN += 1.0f;                      // virtual loss on the decision node itself (Q5/Q6)
+        g.rootW -= 1.0f;
+        int depth = 0;
+        NodeHdr h = load_hdr(node_at(g.abase, cur));
+        while (h.exp_epoch == g.epoch && !(h.flags & F_TERMINAL)) {
+            uint8_t* np = node_at(g.abase, cur);
+            float n = rowN(np)[l], w = rowW(np)[l], p = rowP(np)[l];
+            uint32_t ch = rowC(np)[l];
+            int a;
+            if (G::HAS_PASS && h.legal == 0) {             // pass is the only legal action (mask[64] only)
+                (void)rng_uniform_int(g.rng, 1u);           // bestAction still draws (UCTNode.hpp:250)
+                a = SPRL_PASS;
+            } else {
+                const bool lg = l < G::NA && ((h.legal >> l) & 1ull);
+                const float sq = __builtin_sqrtf(nself);
+                const float den = 1.0f + n;
+                const float q = w / den;                    // UCTNode.hpp:200
+                const float u = p * sq / den;               // UCTNode.hpp:210
+                const float score = q + P.u_weight * u;     // UCTNode.hpp:236
+                const float best = wv::fmax_all(lg ? score : -__builtin_inff());
+                const uint64_t ties = wv::ballot(lg && score == best);
+                const int k = wv::popc64(ties);
+                const int r = rng_uniform_int(g.rng, (uint32_t)k);
+                a = wv::nth_set_bit(ties, r);
+            }
+            g.st.levels++;
+            if (depth >= P.max_depth) { raise_error(P, g, ERR_MAX_DEPTH); return; }
+            if (l == 0) lds_path[depth] = (cur << 8) | (uint32_t)a;
+            ++depth;
+            // ---- getAddChild + the child's virtual loss ----
+            NodeHdr* hp = hdr_of(np);
+            uint32_t c;
+            float n_a, w_a;
+            if (G::HAS_PASS && a == SPRL_PASS) {
+                c = h.passChild;
+                n_a = h.passN;
+                w_a = h.passW;
+            } else {
+                c = wv::bcast_u32(ch, a);
+                n_a = wv::bcast_f32(n, a);
+                w_a = wv::bcast_f32(w, a);
+            }
+            bool created = false;
+            Pos cs;
+            if (c == SPRL_NONE16) {
+                c = g.n_alloc++;
+                created = true;
+                G::child(pos_of(h), a, cs);
+                write_new_node<G>(node_at(g.abase, c), cs, a);
+                w_a = h.value;                              // InitQ::PARENT (UCTNode.hpp:271-273)
+                g.st.nodes_created++;
+                if (G::HAS_PASS && a == SPRL_PASS) hp->passChild = c;
+                else if (l == a) rowC(np)[l] = (uint16_t)c;
+            }
+            if (G::HAS_PASS && a == SPRL_PASS) {
+                hp->passN = n_a + 1.0f;
+                hp->passW = w_a - 1.0f;
+            } else if (l == a) {
+                rowN(np)[l] = n_a + 1.0f;
+                rowW(np)[l] = w_a - 1.0f;
+            }
+            nself = n_a;
+            cur = c;
+            if (created) {
+                // a freshly created node is empty: header known without reloading it
+                h.p0 = cs.p0; h.p1 = cs.p1; h.legal = cs.legal; h.value = 0.0f; h.exp_epoch = 0;
+                h.passChild = SPRL_NONE16; h.player = cs.player; h.winner = cs.winner;
+                h.flags = (uint8_t)((cs.terminal ? F_TERMINAL : 0) | (cs.pass_legal ? F_PASS : 0));
+                break;
+            }
+            h = load_hdr(node_at(g.abase, cur));
+        }
+        // ---- leaf handling (UCTTree.hpp:87-110) ----
+        if (h.flags & F_TERMINAL) {
+            float value = h.winner < 0 ? 0.0f : (h.winner == (int8_t)h.player ? 1.0f : -1.0f);
+            uint32_t e0 = l < depth ? lds_path[l] : 0u;
+            uint32_t e1 = 64 + l < depth ? lds_path[64 + l] : 0u;
+            backup_path<G>(g, e0, e1, depth, h.player, value);
+            g.st.terminal_hits++;
+            continue;
+        } else if (h.flags & F_EVAL) {
+            expand_node<G>(P, g, node_at(g.abase, cur), h, P.add_noise && cur == g.root);
+            uint32_t e0 = l < depth ? lds_path[l] : 0u;
+            uint32_t e1 = 64 + l < depth ? lds_path[64 + l] : 0u;
+            backup_path<G>(g, e0, e1, depth, h.player, h.value);
+            g.st.gray_hits++;
+            continue;
+        } else {
+            const int q = g.n_leaves++;
+            ctl->leaf_node[q] = cur;
+            ctl->leaf_depth[q] = (uint32_t)depth;
+            uint32_t* path = P.paths + ((size_t)slot * SPRL_MAXQ + q) * P.max_depth;
+            if (l < depth) path[l] = lds_path[l];
+            if (64 + l < depth) path[64 + l] = lds_path[64 + l];
+        }
+        if (g.n_leaves >= P.max_queue) break;
+    }
+    g.traversals += trav;
+    g.st.traversals += (unsigned long long)trav;
+    // symmetry draws in queue order (UCTTree.hpp:141-149), then the input planes for the network
+    for (int q = 0; q < g.n_leaves; ++q) {
+        int sym = 0;
+        if (P.use_sym) sym = rng_uniform_int(g.rng, (uint32_t)G::NSYM);
+        ctl->leaf_sym[q] = (uint32_t)sym;
+        if (P.eval_kind == EVAL_NETWORK) {
+            NodeHdr lh = load_hdr(node_at(g.abase, ctl->leaf_node[q]));
+            encode_leaf<G>(P, lh, sym, slot * SPRL_MAXQ + q);
+        }
+    }
+    g.st.nn_evals += (unsigned long long)g.n_leaves;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// arena compaction (rare): Cheney copy of the subtree under the decision node into a spare arena
+// ---------------------------------------------------------------------------------------------------
+SPRL_DEV void copy_node(const uint8_t* src, uint8_t* dst) {
+    struct alignas(16) Chunk { uint32_t x[4]; };
+    ((Chunk*)dst)[wv::lane()] = ((const Chunk*)src)[wv::lane()];
+}
+
+template <class G>
+SPRL_DEV bool compact_arena(const EngineParams& P, Game& g) {
+    const int l = wv::lane();
+    // acquire a spare arena
+    uint32_t got = 0xFFFFFFFFu;
+    if (l == 0) {
+        const uint32_t total = (uint32_t)(P.num_slots + P.num_spare);
+        for (uint32_t i = 0; i < total; ++i) {
+            uint32_t idx = (g.arena + 1 + i) % total;
+            if (wv::atomic_cas_u32(&P.arena_used[idx], 0u, 1u) == 0u) { got = idx; break; }
+        }
+    }
+    got = wv::bcast_u32(got, 0);
+    if (got == 0xFFFFFFFFu) { raise_error(P, g, ERR_NO_SPARE); return false; }
+    uint8_t* from = g.abase;
+    uint8_t* to = P.arenas + (size_t)got * (size_t)P.node_cap * SPRL_NODE_BYTES;
+    copy_node(node_at(from, g.root), node_at(to, 0));
+    wv::wave_fence();
+    uint32_t scan = 0, free_ = 1;
+    while (scan < free_) {
+        uint8_t* np = node_at(to, scan);
+        uint32_t ch = rowC(np)[l];
+        const bool has = ch != SPRL_NONE16;
+        const uint64_t mask = wv::ballot(has);
+        if (has) rowC(np)[l] = (uint16_t)(free_ + (uint32_t)wv::popc64(mask & wv::lt_mask(l)));
+        uint32_t k = 0;
+        for (uint64_t m = mask; m; m &= m - 1, ++k) {
+            uint32_t src = wv::bcast_u32(ch, wv::ctz64(m));
+            copy_node(node_at(from, src), node_at(to, free_ + k));
+        }
+        free_ += k;
+        if (G::HAS_PASS) {
+            NodeHdr* h = hdr_of(np);
+            const uint32_t pc = h->passChild;
+            wv::sync();
+            if (pc != SPRL_NONE16) {
+                copy_node(node_at(from, pc), node_at(to, free_));
+                h->passChild = free_;
+                ++free_;
+            }
+        }
+        wv::wave_fence();
+        ++scan;
+    }
+    if (l == 0) wv::atomic_store_u32(&P.arena_used[g.arena], 0u);
+    g.arena = got;
+    g.abase = to;
+    g.root = 0;
+    g.n_alloc = free_;
+    g.st.compactions++;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// new game / move
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void start_game(const EngineParams& P, Game& g) {
+    uint32_t gid = 0;
+    if (wv::lane() == 0) gid = wv::atomic_add_u32(&P.counters->next_game, 1u);
+    gid = wv::bcast_u32(gid, 0);
+    if (gid >= (uint32_t)P.num_games) {
+        g.status = ST_IDLE;
+        return;
+    }
+    g.status = ST_ACTIVE;
+    g.game_id = gid;
+    rng_seed(g.rng, P.seed, P.stream_base + (int)gid);
+    Pos s;
+    G::start(s);
+    write_new_node<G>(node_at(g.abase, 0), s, 0);
+    g.root = 0;
+    g.n_alloc = 1;
+    g.epoch = 1;
+    g.root_player = 0;
+    g.rootN = 0.0f;                          // UCTTree::m_edgeStatistics slot 0 (UCTTree.hpp:301)
+    g.rootW = 0.0f;
+    g.ply = 0;
+    g.traversals = 0;
+    g.n_leaves = 0;
+    g.st.nodes_created++;
+}
+
+// SelfPlay.hpp:110-148: visit pdf, temperature, CDF sample, record, re-root
+template <class G>
+SPRL_DEV void play_move(const EngineParams& P, Game& g) {
+    const int l = wv::lane();
+    uint8_t* np = node_at(g.abase, g.root);
+    const NodeHdr hcopy = load_hdr(np);
+    const NodeHdr* h = &hcopy;
+    const float visits = l < G::NA ? rowN(np)[l] : 0.0f;
+    const float pass_visits = G::HAS_PASS ? h->passN : 0.0f;
+    // the root row only holds visits on legal actions; everything else is exactly 0 and adds nothing
+    const uint64_t nz = wv::ballot(visits != 0.0f);
+    float sum = 0.0f;
+    for (uint64_t m = nz; m; m &= m - 1) sum += wv::bcast_f32(visits, wv::ctz64(m));
+    if (G::HAS_PASS) sum += pass_visits;
+    float inv = 1.0f / sum;
+    float pdf = visits * inv, pass_pdf = pass_visits * inv;
+    const float ex = g.ply < P.early_cutoff ? P.early_exp : P.rest_exp;
+    pdf = sprl_powf(pdf, ex);
+    pass_pdf = sprl_powf(pass_pdf, ex);
+    sum = 0.0f;
+    for (uint64_t m = nz; m; m &= m - 1) sum += wv::bcast_f32(pdf, wv::ctz64(m));
+    if (G::HAS_PASS) sum += pass_pdf;
+    inv = 1.0f / sum;
+    pdf = pdf * inv;
+    pass_pdf = pass_pdf * inv;
+    // cumsum in index order; lane a ends with the prefix over indices <= a
+    float run = 0.0f, cdf = 0.0f;
+    for (uint64_t m = nz; m; m &= m - 1) {
+        int k = wv::ctz64(m);
+        run += wv::bcast_f32(pdf, k);
+        if (l >= k) cdf = run;
+    }
+    float last = G::HAS_PASS ? run + pass_pdf : wv::bcast_f32(cdf, G::A - 1);
+    inv = 1.0f / last;
+    cdf = cdf * inv;
+    last = last * inv;
+    // record (compact): board, mover, tempered pdf
+    if (g.ply >= P.max_plies) { raise_error(P, g, ERR_MAX_PLIES); return; }
+    const size_t rec = (size_t)g.game_id * (size_t)P.max_plies + (size_t)g.ply;
+    P.rec_boards[rec * 2 + 0] = h->p0;
+    P.rec_boards[rec * 2 + 1] = h->p1;
+    P.rec_movers[rec] = h->player;
+    if (l < G::NA) P.rec_pdf[rec * G::A + l] = pdf;
+    if (G::HAS_PASS) P.rec_pdf[rec * G::A + (G::A - 1)] = pass_pdf;
+    // Random::SampleCDF (utils/random.cpp:86-98)
+    float e;
+    do {
+        e = rng_uniform_float(g.rng);
+    } while (e == 0.0f);
+    const float x = last * e;
+    const uint64_t ge = wv::ballot(l < G::NA && !(cdf < x));
+    const int action = ge ? wv::ctz64(ge) : G::A - 1;
+    // advanceDecision (UCTTree.hpp:197-210): O(1) — follow the edge, carry its stats as the new root's own
+    // N()/W() (Q6), bump the epoch (== clearSubtree), forget the siblings (== pruneChildrenExcept).
+    uint32_t c;
+    float n_a, w_a;
+    if (G::HAS_PASS && action == SPRL_PASS) {
+        c = h->passChild;
+        n_a = h->passN;
+        w_a = h->passW;
+    } else {
+        c = wv::bcast_u32((uint32_t)rowC(np)[l], action);
+        n_a = wv::bcast_f32(visits, action);
+        w_a = wv::bcast_f32(rowW(np)[l], action);
+    }
+    if (c == SPRL_NONE16) {                   // cannot happen for a sampled action (visits > 0); kept for safety
+        Pos cs;
+        G::child(pos_of(*h), action, cs);
+        c = g.n_alloc++;
+        write_new_node<G>(node_at(g.abase, c), cs, action);
+        w_a = (h->flags & F_EVAL) ? h->value : 0.0f;
+    }
+    g.root = c;
+    g.rootN = n_a;
+    g.rootW = w_a;
+    g.root_player ^= 1u;
+    g.ply += 1;
+    g.epoch += 1;
+    g.traversals = 0;
+    g.st.plies++;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one game slot, up to P.rounds rounds
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
+    GameCtl* ctl = P.ctl + slot;
+    Game g;
+    g.status = ctl->status;
+    if (g.status == ST_IDLE || g.status == ST_ERROR) return;
+    g.rng.state = ctl->rng_state;
+    g.rng.inc = ctl->rng_inc;
+    g.game_id = ctl->game_id;
+    g.arena = ctl->arena;
+    g.root = ctl->root;
+    g.n_alloc = ctl->n_alloc;
+    g.epoch = ctl->epoch;
+    g.rootN = ctl->rootN;
+    g.rootW = ctl->rootW;
+    g.ply = ctl->ply;
+    g.traversals = ctl->traversals;
+    g.n_leaves = ctl->n_leaves;
+    g.root_player = ctl->root_player;
+    g.st = ctl->stats;
+    g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * SPRL_NODE_BYTES;
+    wv::sync();
+
+    if (g.status == ST_FRESH) start_game<G>(P, g);
+
+    for (int round = 0; round < P.rounds && g.status == ST_ACTIVE; ++round) {
+        if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl);
+        // while (traversals < numTraversals) ... ; then the move; then the next ply's search begins
+        bool idle = false;
+        while (g.traversals >= P.num_traversals) {
+            play_move<G>(P, g);
+            if (g.status != ST_ACTIVE) break;
+            const NodeHdr rh = load_hdr(node_at(g.abase, g.root));
+            if (rh.flags & F_TERMINAL) {                          // SelfPlay.hpp:85,151
+                P.rec_nplies[g.game_id] = g.ply;
+                P.rec_winner[g.game_id] = rh.winner;
+                g.st.games++;
+                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
+                start_game<G>(P, g);
+                if (g.status != ST_ACTIVE) { idle = true; break; }
+            }
+        }
+        if (idle || g.status != ST_ACTIVE) break;
+        if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) {
+            if (!compact_arena<G>(P, g)) break;
+            if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
+        }
+        select_batch<G>(P, g, slot, ctl, lds_path);
+        if (g.n_alloc > g.st.max_alloc) g.st.max_alloc = g.n_alloc;
+    }
+
+    ctl->status = g.status;
+    ctl->rng_state = g.rng.state;
+    ctl->rng_inc = g.rng.inc;
+    ctl->game_id = g.game_id;
+    ctl->arena = g.arena;
+    ctl->root = g.root;
+    ctl->n_alloc = g.n_alloc;
+    ctl->epoch = g.epoch;
+    ctl->rootN = g.rootN;
+    ctl->rootW = g.rootW;
+    ctl->ply = g.ply;
+    ctl->traversals = g.traversals;
+    ctl->n_leaves = g.n_leaves;
+    ctl->root_player = g.root_player;
+    ctl->stats = g.st;
+    if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
+}
+
+}  // namespace sprl
+
+#endif  // SPRL_STEP_KERNEL_H

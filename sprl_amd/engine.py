@@ -1,0 +1,229 @@
+"""ctypes binding of libsprl_amd.so (include/sprl_amd.h) — the Python face of the C ABI.
+
+Host-side mirror of the reference's `runIteration` (cpp/src/selfplay/SelfPlay.hpp:204-248) and record
+writer (cpp/src/selfplay/GridWorker.hpp:146-196).  The search runs in hand-written gfx950 kernels; there
+is no CPU fallback: importing works anywhere, creating an engine without an MI355X raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libsprl_amd.so")
+
+OTHELLO, CONNECT_FOUR = 0, 1
+EVAL_RANDOM, EVAL_HEURISTIC, EVAL_NETWORK = 0, 1, 2
+MASK_REFERENCE, MASK_SYMMETRISED = 0, 1
+GAME_IDS = {"othello": OTHELLO, "connect_four": CONNECT_FOUR, "c4": CONNECT_FOUR}
+
+
+class SprlError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"sprl_amd error {code}: {message}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("game", C.c_int32), ("device", C.c_int32), ("concurrent_games", C.c_int32), ("num_traversals", C.c_int32),
+        ("max_batch", C.c_int32), ("max_queue", C.c_int32), ("dir_eps", C.c_float), ("dir_alpha", C.c_float),
+        ("u_weight", C.c_float), ("early_cutoff", C.c_int32), ("early_exp", C.c_float), ("rest_exp", C.c_float),
+        ("use_symmetry", C.c_int32), ("add_noise", C.c_int32), ("mask_frame", C.c_int32), ("node_cap", C.c_int32),
+        ("spare_arenas", C.c_int32), ("max_plies", C.c_int32), ("seed", C.c_uint64), ("stream_base", C.c_int32),
+        ("profile", C.c_int32),
+    ]
+
+
+class Records(C.Structure):
+    _fields_ = [
+        ("game", C.c_int32), ("num_games", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+        ("cells", C.c_int32), ("actions", C.c_int32), ("nsym", C.c_int32), ("use_symmetry", C.c_int32),
+        ("total_plies", C.c_int64), ("ply_offset", C.POINTER(C.c_int32)), ("boards", C.POINTER(C.c_int8)),
+        ("movers", C.POINTER(C.c_int8)), ("pdfs", C.POINTER(C.c_float)), ("winners", C.POINTER(C.c_int8)),
+        ("owner_", C.c_void_p),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "games", "plies", "traversals", "levels", "expansions", "nn_evals", "terminal_hits", "gray_hits",
+        "dup_hits", "nodes_created", "compactions", "max_nodes_in_arena", "rounds", "kernel_launches",
+        "nn_batches")] + [("seconds_total", C.c_double), ("kernel_ms", C.c_double), ("nn_ms", C.c_double),
+                          ("hbm_bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+FORWARD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+
+_libs = {}
+
+
+def load_library(path=None):
+    """Load the C-ABI library.  `path` defaults to the in-tree gfx950 build; a missing library is an error."""
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise SprlError(-4, f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.sprl_last_error.restype = C.c_char_p
+    L.sprl_config_default.argtypes = [C.c_int32, C.POINTER(Config)]
+    L.sprl_engine_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.sprl_engine_destroy.argtypes = [C.c_void_p]
+    L.sprl_engine_destroy.restype = None
+    L.sprl_engine_set_model.argtypes = [C.c_void_p, C.c_char_p]
+    L.sprl_engine_set_forward.argtypes = [C.c_void_p, FORWARD_FN, C.c_void_p]
+    L.sprl_engine_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Records)]
+    L.sprl_engine_begin.argtypes = [C.c_void_p, C.c_int32]
+    L.sprl_engine_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.sprl_engine_collect.argtypes = [C.c_void_p, C.POINTER(Records)]
+    L.sprl_records_free.argtypes = [C.POINTER(Records)]
+    L.sprl_records_free.restype = None
+    L.sprl_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.sprl_records_num_samples.argtypes = [C.POINTER(Records)]
+    L.sprl_records_num_samples.restype = C.c_int64
+    L.sprl_records_expand.argtypes = [C.POINTER(Records), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sprl_records_expand_boards.argtypes = [C.POINTER(Records), C.c_void_p, C.c_void_p]
+    L.sprl_write_npy.argtypes = [C.c_char_p, C.POINTER(Records)]
+    _libs[path] = L
+    return L
+
+
+def default_config(game, lib=None, **overrides):
+    L = lib or load_library()
+    cfg = Config()
+    gid = GAME_IDS[game] if isinstance(game, str) else game
+    rc = L.sprl_config_default(gid, C.byref(cfg))
+    if rc:
+        raise SprlError(rc, L.sprl_last_error().decode())
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(f"sprl_config has no field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+class SelfPlayRecords:
+    """Owns one sprl_records; exposes numpy views/copies and the reference's expanded sample arrays."""
+
+    def __init__(self, lib, rec):
+        self._lib, self._rec = lib, rec
+        r = rec
+        n, ng = r.total_plies, r.num_games
+        self.game, self.num_games, self.total_plies = r.game, ng, n
+        self.rows, self.cols, self.cells, self.actions, self.nsym = r.rows, r.cols, r.cells, r.actions, r.nsym
+        self.use_symmetry = bool(r.use_symmetry)
+        self.ply_offset = np.ctypeslib.as_array(r.ply_offset, shape=(ng + 1,)).copy()
+        self.boards = np.ctypeslib.as_array(r.boards, shape=(n, r.cells)).copy()
+        self.movers = np.ctypeslib.as_array(r.movers, shape=(n,)).copy()
+        self.pdfs = np.ctypeslib.as_array(r.pdfs, shape=(n, r.actions)).copy()
+        self.winners = np.ctypeslib.as_array(r.winners, shape=(ng,)).copy()
+
+    @property
+    def num_samples(self):
+        return int(self._lib.sprl_records_num_samples(C.byref(self._rec)))
+
+    def expand(self):
+        """(states float32[N,3,R,C], distributions float32[N,A], outcomes float32[N]) — GridWorker.hpp:146-196."""
+        n = self.num_samples
+        states = np.zeros((n, 3, self.rows, self.cols), np.float32)
+        dists = np.zeros((n, self.actions), np.float32)
+        outs = np.zeros(n, np.float32)
+        rc = self._lib.sprl_records_expand(C.byref(self._rec), states.ctypes.data, dists.ctypes.data, outs.ctypes.data)
+        if rc:
+            raise SprlError(rc, self._lib.sprl_last_error().decode())
+        return states, dists, outs
+
+    def expand_boards(self):
+        n = self.num_samples
+        boards = np.zeros((n, self.cells), np.int8)
+        players = np.zeros(n, np.int8)
+        rc = self._lib.sprl_records_expand_boards(C.byref(self._rec), boards.ctypes.data, players.ctypes.data)
+        if rc:
+            raise SprlError(rc, self._lib.sprl_last_error().decode())
+        return boards, players
+
+    def write_npy(self, path_prefix):
+        rc = self._lib.sprl_write_npy(os.fsencode(path_prefix), C.byref(self._rec))
+        if rc:
+            raise SprlError(rc, self._lib.sprl_last_error().decode())
+
+    def close(self):
+        if self._rec is not None:
+            self._lib.sprl_records_free(C.byref(self._rec))
+            self._rec = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One self-play engine on one GPU (sprl_engine_*)."""
+
+    def __init__(self, cfg, lib=None):
+        self._lib = lib or load_library()
+        self._h = C.c_void_p()
+        self._cb = None
+        self.cfg = cfg
+        rc = self._lib.sprl_engine_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            raise SprlError(rc, self._lib.sprl_last_error().decode())
+
+    def _check(self, rc):
+        if rc:
+            raise SprlError(rc, self._lib.sprl_last_error().decode())
+
+    def set_model(self, model):
+        self._check(self._lib.sprl_engine_set_model(self._h, os.fsencode(model)))
+
+    def set_forward(self, fn):
+        """fn(planes_ptr, batch, logits_ptr, value_ptr) -> int, all DEVICE pointers (ints)."""
+        def _cb(user, planes, batch, logits, value):
+            try:
+                return int(fn(planes, batch, logits, value) or 0)
+            except Exception as exc:  # never let an exception cross the C boundary
+                print("forward callback failed:", exc)
+                return -1
+        self._cb = FORWARD_FN(_cb)
+        self._check(self._lib.sprl_engine_set_forward(self._h, self._cb, None))
+
+    def run(self, num_games):
+        rec = Records()
+        self._check(self._lib.sprl_engine_run(self._h, num_games, C.byref(rec)))
+        return SelfPlayRecords(self._lib, rec)
+
+    def begin(self, num_games):
+        self._check(self._lib.sprl_engine_begin(self._h, num_games))
+
+    def step(self, rounds):
+        done, active = C.c_int32(), C.c_int32()
+        self._check(self._lib.sprl_engine_step(self._h, rounds, C.byref(done), C.byref(active)))
+        return done.value, active.value
+
+    def collect(self):
+        rec = Records()
+        self._check(self._lib.sprl_engine_collect(self._h, C.byref(rec)))
+        return SelfPlayRecords(self._lib, rec)
+
+    def stats(self):
+        st = Stats()
+        self._check(self._lib.sprl_engine_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            self._lib.sprl_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

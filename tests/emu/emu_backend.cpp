@@ -1,0 +1,56 @@
+// TEST INFRASTRUCTURE — backend.h on the CPU SIMT emulator (see emu_runtime.cpp).  Builds
+// tests/emu/libsprl_emu.so = engine.cpp + the product kernel source compiled with -DSPRL_EMU, so that
+// `pytest -m "not gpu"` can check kernel logic against the oracle without a GPU.  Never shipped, never
+// loaded by the sprl_amd package.
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+
+#include "../../sprl_amd/csrc/backend.h"
+#include "../../sprl_amd/csrc/step_kernel.h"
+
+namespace emu {
+typedef void (*block_fn)(void* arg, int block);
+void launch(block_fn fn, void* arg, int nblocks);
+}
+
+namespace {
+static thread_local uint32_t tl_lds[256];
+
+template <class G>
+void block_entry(void* arg, int block) {
+    const EngineParams* P = (const EngineParams*)arg;
+    sprl::step_game<G>(*P, block, tl_lds);
+}
+}  // namespace
+
+namespace be {
+const char* name() { return "cpu-simt-emulator (tests only)"; }
+const char* last_error() { return "emulator error"; }
+bool available(std::string*) { return true; }
+int init(int, std::string*) { return 0; }
+void* dmalloc(size_t bytes) { return calloc(1, bytes); }
+void dfree(void* p) { free(p); }
+int h2d(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return 0; }
+int d2h(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return 0; }
+int dmemset(void* dst, int v, size_t n) { memset(dst, v, n); return 0; }
+int sync() { return 0; }
+int launch_step(int game, const EngineParams& P) {
+    EngineParams copy = P;
+    if (game == SPRL_GAME_OTHELLO) emu::launch(block_entry<Othello>, &copy, P.num_slots);
+    else emu::launch(block_entry<ConnectFour>, &copy, P.num_slots);
+    return 0;
+}
+void* mark() {
+    auto* t = new std::chrono::steady_clock::time_point(std::chrono::steady_clock::now());
+    return t;
+}
+double elapsed_ms(void* a, void* b) {
+    auto* ta = (std::chrono::steady_clock::time_point*)a;
+    auto* tb = (std::chrono::steady_clock::time_point*)b;
+    return std::chrono::duration<double, std::milli>(*tb - *ta).count();
+}
+void mark_free(void* m) { delete (std::chrono::steady_clock::time_point*)m; }
+}  // namespace be

@@ -1,0 +1,69 @@
+"""Shared parity checks: an engine library (gfx950 build on the GPU box, SIMT-emulator build on CPU)
+against the CPU oracle in portable-math mode.  Bit-exact: boards, movers, pdf bits, outcomes, counters."""
+import numpy as np
+
+from oracle import pyoracle as po
+from sprl_amd import engine as E
+
+OGAME = {"othello": po.GAME_OTHELLO, "c4": po.GAME_C4}
+
+
+def oracle_config(game, cfg, kind, forward=None):
+    return po.make_config(OGAME[game], cfg.num_traversals, max_batch=cfg.max_batch, max_queue=cfg.max_queue,
+                          dir_eps=cfg.dir_eps, dir_alpha=cfg.dir_alpha, u_weight=cfg.u_weight,
+                          early_cutoff=cfg.early_cutoff, early_exp=cfg.early_exp, rest_exp=cfg.rest_exp,
+                          use_sym=cfg.use_symmetry, add_noise=cfg.add_noise, eval_kind=kind,
+                          math_mode=po.MATH_PORTABLE, mask_frame=cfg.mask_frame, forward=forward)
+
+
+def run_engine(lib, game, num_games, model="random", forward=None, **cfg_kw):
+    cfg = E.default_config(game, lib, **cfg_kw)
+    eng = E.Engine(cfg, lib)
+    if forward is not None:
+        eng.set_forward(forward)
+    else:
+        eng.set_model(model)
+    rec = eng.run(num_games)
+    st = eng.stats()
+    eng.close()
+    return cfg, rec, st
+
+
+def assert_same_games(rec, ora):
+    boards, players = rec.expand_boards()
+    _, dists, outcomes = rec.expand()
+    assert boards.shape == ora["boards"].shape, (boards.shape, ora["boards"].shape)
+    assert (boards == ora["boards"]).all()
+    assert (players == ora["players"]).all()
+    assert (dists.view(np.uint32) == ora["dists"].view(np.uint32)).all()
+    assert (outcomes == ora["outcomes"]).all()
+    nsym = rec.nsym if rec.use_symmetry else 1
+    assert (rec.ply_offset * nsym == ora["offsets"]).all()
+
+
+def assert_same_counters(st, ost):
+    for k in ("games", "plies", "traversals", "levels", "expansions", "nn_evals", "terminal_hits", "gray_hits",
+              "dup_hits", "nodes_created"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+
+
+def check_case(lib, game, num_games, model="random", seed=7, **cfg_kw):
+    kind = {"random": po.EVAL_RANDOM, "heuristic": po.EVAL_HEURISTIC}[model]
+    cfg, rec, st = run_engine(lib, game, num_games, model, seed=seed, **cfg_kw)
+    ora = po.selfplay(oracle_config(game, cfg, kind), num_games, seed, cfg.stream_base, True)
+    assert_same_games(rec, ora)
+    assert_same_counters(st, ora["stats"])
+    return rec, st
+
+
+def toy_forward_numpy(planes, A):
+    """A deterministic stand-in network evaluated sample by sample in float64 (so that batch composition
+    cannot change a bit): logits from fixed pseudo-random projections of the planes, value = tanh."""
+    n = planes.shape[0]
+    x = planes.reshape(n, -1).astype(np.float64)
+    rng = np.random.default_rng(1234)
+    w = rng.standard_normal((x.shape[1], A)) * 0.35
+    v = rng.standard_normal(x.shape[1]) * 0.2
+    logits = np.stack([x[i] @ w for i in range(n)]).astype(np.float32)
+    value = np.tanh(np.array([x[i] @ v for i in range(n)])).astype(np.float32)
+    return logits, value

@@ -1,0 +1,108 @@
+"""Kernel-logic parity WITHOUT a GPU: the product kernel source (sprl_amd/csrc/step_kernel.h) compiled for
+the CPU SIMT emulator (tests/emu) must reproduce the oracle's self-play games bit for bit.  The emulator is
+test infrastructure only — the GPU parity tests proper are in test_gpu_parity.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from sprl_amd import engine as E
+import parity
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    return E.load_library(os.path.join(EMU_DIR, "libsprl_emu.so"))
+
+
+def test_c4_random(emu):
+    parity.check_case(emu, "c4", 3, concurrent_games=2, num_traversals=40)
+
+
+def test_othello_random(emu):
+    parity.check_case(emu, "othello", 2, concurrent_games=2, num_traversals=30)
+
+
+def test_othello_heuristic(emu):
+    parity.check_case(emu, "othello", 2, model="heuristic", concurrent_games=2, num_traversals=30)
+
+
+def test_othello_compaction_with_tiny_arena(emu):
+    rec, st = parity.check_case(emu, "othello", 2, concurrent_games=2, num_traversals=40, node_cap=120,
+                                spare_arenas=2)
+    assert st["compactions"] > 0 and st["max_nodes_in_arena"] <= 120
+
+
+def test_othello_no_symmetry_no_noise_batch1(emu):
+    parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=25, use_symmetry=0, add_noise=0,
+                      max_batch=1, max_queue=1)
+
+
+def test_othello_symmetrised_mask_option(emu):
+    parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=30, mask_frame=E.MASK_SYMMETRISED)
+
+
+def test_more_games_than_slots_and_stream_base(emu):
+    rec, st = parity.check_case(emu, "c4", 5, concurrent_games=2, num_traversals=30, seed=99, stream_base=17)
+    assert rec.num_games == 5 and st["games"] == 5
+
+
+def test_network_path_toy_forward(emu):
+    """Encode (symmetrised planes) -> forward -> decode (exp / wrong-frame mask / normalise / inverse symmetry)
+    through the callback evaluator, against the oracle's restatement of GridNetwork::evaluate."""
+    A, cells = 65, 64
+
+    def engine_forward(planes_ptr, batch, logits_ptr, value_ptr):
+        planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_float)), shape=(batch, 3, 8, 8))
+        lo, va = parity.toy_forward_numpy(planes, A)
+        np.ctypeslib.as_array(C.cast(logits_ptr, C.POINTER(C.c_float)), shape=(batch, A))[:] = lo
+        np.ctypeslib.as_array(C.cast(value_ptr, C.POINTER(C.c_float)), shape=(batch,))[:] = va
+        return 0
+
+    cfg, rec, st = parity.run_engine(emu, "othello", 2, forward=engine_forward, concurrent_games=2,
+                                     num_traversals=24, seed=5)
+    cb = po.make_forward(lambda x: parity.toy_forward_numpy(x, A), po.GAME_OTHELLO)
+    ora = po.selfplay(parity.oracle_config("othello", cfg, po.EVAL_CALLBACK, forward=cb), 2, 5, 1, True)
+    parity.assert_same_games(rec, ora)
+    parity.assert_same_counters(st, ora["stats"])
+
+
+def test_npy_files_match_oracle_writer(emu, tmp_path):
+    cfg, rec, _ = parity.run_engine(emu, "c4", 2, concurrent_games=2, num_traversals=30, seed=3)
+    rec.write_npy(str(tmp_path / "run_iteration_0"))
+    ocfg = parity.oracle_config("c4", cfg, po.EVAL_RANDOM)
+    ora = po.selfplay(ocfg, 2, 3, 1, True)
+    po.write_records(ocfg, str(tmp_path / "ora_iteration_0"), ora)
+    for part in ("states", "distributions", "outcomes"):
+        a = open(tmp_path / f"run_iteration_0_{part}.npy", "rb").read()
+        b = open(tmp_path / f"ora_iteration_0_{part}.npy", "rb").read()
+        assert a == b, part
+    assert not list(tmp_path.glob("*.tmp"))
+    s = np.load(tmp_path / "run_iteration_0_states.npy")
+    assert s.dtype == np.float32 and s.shape[1:] == (3, 6, 7)
+
+
+def test_error_codes(emu):
+    cfg = E.default_config("othello", emu, concurrent_games=1, num_traversals=40, node_cap=40, spare_arenas=1)
+    eng = E.Engine(cfg, emu)
+    with pytest.raises(E.SprlError) as ei:
+        eng.run(1)
+    assert ei.value.code == -3          # SPRL_E_NODEPOOL: live subtree cannot fit 40 nodes
+    eng.close()
+    for bad in (dict(max_queue=9), dict(num_traversals=0), dict(stream_base=0), dict(concurrent_games=0)):
+        with pytest.raises(E.SprlError) as ei:
+            E.Engine(E.default_config("othello", emu, **bad), emu)
+        assert ei.value.code == -1
+    eng = E.Engine(E.default_config("c4", emu, concurrent_games=1), emu)
+    with pytest.raises(E.SprlError):
+        eng.set_model("heuristic")      # Othello only
+    with pytest.raises(E.SprlError) as ei:
+        eng.step(1)                     # begin() not called
+    assert ei.value.code == -5
+    eng.close()

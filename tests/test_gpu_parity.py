@@ -1,0 +1,138 @@
+"""GPU parity tests proper (run with -m gpu on the MI355X box): the hand-written gfx950 kernels, called through
+the C ABI, against the CPU oracle on the same seeds.  Bit-exact for boards, movers, pdf bits, outcomes and
+search counters; the CNN path is compared within the tolerance stated in each test."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from sprl_amd import engine as E
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = E.load_library()          # raises if the gfx950 build is missing: no fallback
+    assert L.sprl_device_available() == 1, "no MI355X visible"
+    return L
+
+
+@pytest.fixture(scope="module")
+def traced_model(tmp_path_factory):
+    from sprl_amd.network import make_network, trace_to_file
+    d = tmp_path_factory.mktemp("model")
+    return trace_to_file(make_network("othello", 2, 64, seed=0), str(d / "traced_oth.pt"), "othello")
+
+
+def test_othello_random_whole_games(lib):
+    parity.check_case(lib, "othello", 6, concurrent_games=4, num_traversals=100)
+
+
+def test_othello_heuristic_whole_games(lib):
+    parity.check_case(lib, "othello", 4, model="heuristic", concurrent_games=4, num_traversals=100)
+
+
+def test_othello_800_traversals_reference_budget(lib):
+    """BASELINE config: 800 traversals/move, batch 8 / queue 4, Dirichlet (0.25, 0.3), D4."""
+    rec, st = parity.check_case(lib, "othello", 3, concurrent_games=3, num_traversals=800, seed=2024)
+    assert st["compactions"] == 0
+
+
+def test_c4_reference_config(lib):
+    """BASELINE configs[0]: Connect Four, 100 traversals/move (reference CPU-runnable case)."""
+    parity.check_case(lib, "c4", 16, concurrent_games=8, num_traversals=100)
+
+
+def test_compaction_tiny_arena(lib):
+    rec, st = parity.check_case(lib, "othello", 4, concurrent_games=4, num_traversals=60, node_cap=160, spare_arenas=4)
+    assert st["compactions"] > 0
+
+
+def test_batch1_queue1_nosym_nonoise(lib):
+    parity.check_case(lib, "othello", 2, concurrent_games=2, num_traversals=50, use_symmetry=0, add_noise=0,
+                      max_batch=1, max_queue=1)
+
+
+def test_symmetrised_mask_option(lib):
+    parity.check_case(lib, "othello", 2, concurrent_games=2, num_traversals=50, mask_frame=E.MASK_SYMMETRISED)
+
+
+def test_many_concurrent_games_are_independent(lib):
+    """Game g must not depend on how many games run beside it: 256 slots vs the oracle one game at a time."""
+    parity.check_case(lib, "othello", 256, concurrent_games=256, num_traversals=24, seed=5)
+
+
+def test_network_toy_forward_callback(lib):
+    """Encode -> forward -> decode through DEVICE buffers with a deterministic stand-in network."""
+    import torch
+    A = 65
+
+    def fwd(planes_ptr, batch, logits_ptr, value_ptr):
+        class _Arr:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = dict(shape=shape, typestr="<f4", data=(ptr, False), version=2)
+        x = torch.as_tensor(_Arr(planes_ptr, (batch, 3, 8, 8)), device="cuda").cpu().numpy()
+        lo, va = parity.toy_forward_numpy(x, A)
+        torch.as_tensor(_Arr(logits_ptr, (batch, A)), device="cuda").copy_(torch.from_numpy(lo))
+        torch.as_tensor(_Arr(value_ptr, (batch,)), device="cuda").copy_(torch.from_numpy(va))
+        torch.cuda.synchronize()
+        return 0
+
+    cfg, rec, st = parity.run_engine(lib, "othello", 2, forward=fwd, concurrent_games=2, num_traversals=24, seed=5)
+    cb = po.make_forward(lambda x: parity.toy_forward_numpy(x, A), po.GAME_OTHELLO)
+    ora = po.selfplay(parity.oracle_config("othello", cfg, po.EVAL_CALLBACK, forward=cb), 2, 5, 1, True)
+    parity.assert_same_games(rec, ora)
+    parity.assert_same_counters(st, ora["stats"])
+
+
+def test_torchscript_cnn_through_libtorch(lib, traced_model):
+    """The LibTorch-ROCm evaluator: records are valid and the device evaluations agree with a CPU fp32 forward
+    of the same TorchScript file to 1e-4 (abs) on logits / value for the recorded positions."""
+    import torch
+    cfg, rec, st = parity.run_engine(lib, "othello", 4, model=traced_model, concurrent_games=4, num_traversals=64)
+    states, dists, outcomes = rec.expand()
+    assert st["games"] == 4 and st["nn_batches"] > 0 and st["nn_evals"] > 0
+    assert np.allclose(dists.sum(1), 1.0, atol=1e-4)
+    assert set(np.unique(outcomes).tolist()) <= {-1.0, 0.0, 1.0}
+    m_cpu = torch.jit.load(traced_model, map_location="cpu").eval()
+    m_gpu = torch.jit.load(traced_model, map_location="cuda").eval()
+    x = torch.from_numpy(states[:512])
+    with torch.no_grad():
+        lc, vc = m_cpu(x)
+        lg, vg = m_gpu(x.cuda())
+    np.testing.assert_allclose(lg.cpu().numpy(), lc.numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(vg.cpu().numpy(), vc.numpy(), atol=1e-4, rtol=0)
+
+
+def test_full_size_properties(lib):
+    """BASELINE-sized launch geometry (4096 resident games) on a short budget: size-independent properties —
+    pdfs are distributions supported on legal moves, outcomes antisymmetric per game, plies consistent."""
+    cfg, rec, st = parity.run_engine(lib, "othello", 4096, concurrent_games=4096, num_traversals=16, seed=3)
+    assert rec.num_games == 4096 and st["games"] == 4096 and st["compactions"] == 0
+    assert np.allclose(rec.pdfs.sum(1), 1.0, atol=1e-5)
+    assert (np.diff(rec.ply_offset) >= 9).all() and (np.diff(rec.ply_offset) <= 128).all()
+    occupied = rec.boards[:, :64] >= 0
+    assert (rec.pdfs[:, :64][occupied] == 0).all()        # no probability on occupied squares
+    # spot-check 8 games against the oracle
+    ora = po.selfplay(parity.oracle_config("othello", cfg, po.EVAL_RANDOM), 8, 3, 1, True)
+    b, p = rec.expand_boards()
+    n = len(ora["players"])
+    assert (b[:n] == ora["boards"]).all() and (p[:n] == ora["players"]).all()
+
+
+def test_npy_roundtrip(lib, tmp_path):
+    cfg, rec, _ = parity.run_engine(lib, "c4", 3, concurrent_games=3, num_traversals=50, seed=3)
+    rec.write_npy(str(tmp_path / "run_iteration_0"))
+    s = np.load(tmp_path / "run_iteration_0_states.npy")
+    d = np.load(tmp_path / "run_iteration_0_distributions.npy")
+    o = np.load(tmp_path / "run_iteration_0_outcomes.npy")
+    assert s.shape[0] == d.shape[0] == o.shape[0] == rec.num_samples and s.shape[1:] == (3, 6, 7)
+    ocfg = parity.oracle_config("c4", cfg, po.EVAL_RANDOM)
+    ora = po.selfplay(ocfg, 3, 3, 1, True)
+    po.write_records(ocfg, str(tmp_path / "ora_iteration_0"), ora)
+    for part in ("states", "distributions", "outcomes"):
+        assert open(tmp_path / f"run_iteration_0_{part}.npy", "rb").read() == \
+            open(tmp_path / f"ora_iteration_0_{part}.npy", "rb").read()
