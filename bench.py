@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py — self-play games/sec (+ UCT node-expansions/sec) on MI355X, Othello 8x8 @ 800 iters/move.
+
+A *step* is one self-play iteration in the reference's sense (runIteration, cpp/src/selfplay/SelfPlay.hpp:204-248):
+every GPU plays `--games` games (default = its 4096 resident game slots) from the start position to the end,
+with the reference worker's search constants (OTHWorker.cpp:24-28, constants.hpp:6-10), a random-init
+2-block x 64-channel policy/value CNN evaluated in fp32 through LibTorch-ROCm, D4 symmetrisation, Dirichlet
+noise, parent-Q init and sub-tree reuse, and emits the compact self-play records (gathered to rank 0 over RCCL
+when N > 1).  Inputs are synthetic by construction (all games start from the rules' start position, weights are
+random-init); everything is resident in HBM when the timed region starts.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run, one rank per GPU).
+W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; MAX over ranks; rank 0
+prints ONE JSON line.  `value` = whole-job games/sec.  Weak scaling: per-GPU work is fixed as N grows.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_traversal(st, A=65, mask_bytes=8, board_bytes=64, s_in=3 * 64 * 4):
+    """SURVEY.md §8(d) per-traversal figure, recomputed with this run's measured search shape."""
+    trav = max(1, st["traversals"])
+    D = st["levels"] / trav
+    f_nn = st["nn_evals"] / trav
+    f_g = st["gray_hits"] / trav
+    select = D * (3 * A * 4 + mask_bytes + 4 + 4) + (D + 1) * 16
+    backup = (D + 1) * 8
+    expand = (f_nn + f_g) * (A * 4 + A * 4)
+    create = f_nn * (2 * A * 4 + board_bytes * 2 + mask_bytes)
+    leaf_io = f_nn * (s_in * 2 + (A + 1) * 4 * 2 + A * 4)
+    return select + backup + expand + create + leaf_io, dict(D=D, f_nn=f_nn, f_gray=f_g)
+
+
+def _cpu_worker(args):
+    """One single-threaded reference worker process: the reference's selfPlay + GridNetwork on LibTorch-CPU."""
+    model, games, trav, stream = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["MKL_NUM_THREADS"] = "1"
+    import torch
+    torch.set_num_threads(1)
+    from oracle import pyref
+    t0 = time.time()
+    r = pyref.selfplay("othello", 0, games, trav, 8, 4, 0.25, 0.3, 4242, stream, True, model_path=model)
+    return time.time() - t0, games, r["evals"], len(r["players"])
+
+
+def cpu_baseline(model_path, traversals, budget_games_per_core=1):
+    """Reference CPU path timed on this box's host cores (bounded sample).  kind = "reference" when the prebuilt
+    oracle/_ref library (the reference's own sources compiled in place) travelled with the repo, else the
+    oracle ("port") with a LibTorch-CPU forward callback."""
+    import multiprocessing as mp
+    from oracle import pyref
+    cores = max(1, min(16, os.cpu_count() or 1))
+    if pyref.available(True):
+        ctx = mp.get_context("spawn")
+        t0 = time.time()
+        with ctx.Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(model_path, budget_games_per_core, traversals, 1000 + i) for i in range(cores)])
+        wall = time.time() - t0
+        games = sum(r[1] for r in res)
+        evals = sum(r[2] for r in res)
+        per_proc = max(r[0] for r in res)
+        return {"value": games / per_proc, "unit": "games/s", "cores": cores, "kind": "reference",
+                "sample": f"{cores} single-thread processes x {budget_games_per_core} game(s), Othello {traversals} it/move, "
+                          f"batch 8/queue 4, same traced 2x64 CNN on LibTorch-CPU, -O3 -DNDEBUG; slowest process "
+                          f"{per_proc:.1f}s (pool wall {wall:.1f}s), {evals} network evals",
+                "games_per_sec_per_core": games / per_proc / cores, "evals_per_sec": evals / per_proc}
+    # fallback: the oracle with a torch-CPU forward (scalar port, 1 core)
+    import torch
+    from oracle import pyoracle as po
+    torch.set_num_threads(1)
+    net = torch.jit.load(model_path, map_location="cpu").eval()
+
+    def fwd(x):
+        with torch.no_grad():
+            lo, va = net(torch.from_numpy(x))
+        return lo.numpy(), va.numpy()
+
+    cb = po.make_forward(fwd, po.GAME_OTHELLO)
+    cfg = po.make_config(po.GAME_OTHELLO, traversals, eval_kind=po.EVAL_CALLBACK, forward=cb)
+    t0 = time.time()
+    r = po.selfplay(cfg, 1, 4242, 1000, True)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "games/s", "cores": 1, "kind": "port",
+            "sample": f"1 game, Othello {traversals} it/move, oracle + torch-CPU forward, {r['stats']['nn_evals']} evals"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--games", type=int, default=0, help="games per GPU per step (default: = --concurrent)")
+    ap.add_argument("--concurrent", type=int, default=4096, help="resident game slots per GPU")
+    ap.add_argument("--traversals", type=int, default=800)
+    ap.add_argument("--model", default="cnn", choices=["cnn", "random", "heuristic"],
+                    help="cnn = BASELINE config (traced 2x64 CNN via LibTorch-ROCm); random/heuristic = tree kernels only")
+    ap.add_argument("--blocks", type=int, default=2)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--rounds-per-call", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no MI355X visible (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from sprl_amd import engine as E
+    from sprl_amd.network import make_network, trace_to_file
+
+    games = args.games or args.concurrent
+    lib = E.load_library()
+    tmpdir = tempfile.mkdtemp(prefix="sprl_bench_")
+    model_path = None
+    if args.model == "cnn":
+        model_path = trace_to_file(make_network("othello", args.blocks, args.channels, seed=0),
+                                   os.path.join(tmpdir, f"traced_bench_r{rank}.pt"), "othello")
+    total_steps = args.steps + args.warmup
+    # unique RNG streams for every game of every step of every rank
+    cfg = E.default_config("othello", lib, device=local_rank, concurrent_games=args.concurrent,
+                           num_traversals=args.traversals, seed=args.seed,
+                           stream_base=1 + rank * games * (total_steps + 1), profile=0 if args.no_profile else 1)
+    eng = E.Engine(cfg, lib)
+    eng.set_model(model_path if model_path else args.model)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def gather_records(rec):
+        """RCCL gather of the compact finished-game records to rank 0: equal-sized padded shards."""
+        if dist is None:
+            return rec.total_plies
+        import numpy as np
+        cap = games * cfg_max_plies
+        buf = np.zeros((cap, 16 + 1 + rec.actions * 4), np.uint8)
+        n = rec.total_plies
+        packed = np.zeros((n, 64), np.int8)
+        packed[:, :rec.cells] = rec.boards
+        buf[:n, :16] = np.packbits((packed[:, :64] == 0), axis=1, bitorder="little").view(np.uint8).reshape(n, 8).repeat(1, axis=1).tolist() if False else 0
+        # boards as two bit-planes (player ZERO / ONE), mover, pdf
+        b0 = np.packbits(packed == 0, axis=1, bitorder="little")
+        b1 = np.packbits(packed == 1, axis=1, bitorder="little")
+        buf[:n, 0:8] = b0
+        buf[:n, 8:16] = b1
+        buf[:n, 16] = rec.movers.view(np.uint8)
+        buf[:n, 17:] = rec.pdfs.view(np.uint8).reshape(n, -1)
+        t = torch.from_numpy(buf).cuda()
+        meta = torch.tensor([n, rec.num_games], device="cuda", dtype=torch.int64)
+        metas = [torch.zeros_like(meta) for _ in range(world)] if rank == 0 else None
+        outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(meta, metas, dst=0)
+        dist.gather(t, outs, dst=0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            return int(sum(int(m[0]) for m in metas))
+        return n
+
+    cfg_max_plies = 128
+
+    def one_step():
+        eng.begin(games)
+        done = 0
+        while done < games:
+            done, _ = eng.step(args.rounds_per_call)
+        rec = eng.collect()
+        plies = gather_records(rec)
+        rec.close()
+        return plies
+
+    # untimed primer: model load, MIOpen kernel selection, first-touch of the arenas
+    eng.begin(games)
+    eng.step(4)
+    barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    st0 = eng.stats()
+    barrier()
+    t0 = time.perf_counter()
+    plies = 0
+    for _ in range(args.steps):
+        plies += one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st1 = eng.stats()
+    d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
+
+    if rank == 0:
+        total_games = games * args.steps * world
+        bpt, shape = algorithmic_bytes_per_traversal(d)
+        out = {
+            "metric": "self-play games/sec, Othello 8x8 @ 800 iters/move" if args.traversals == 800 else
+                      f"self-play games/sec, Othello 8x8 @ {args.traversals} iters/move",
+            "value": total_games / elapsed,
+            "unit": "games/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / max(1, args.steps),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (start-position self-play, random-init weights)",
+            "config": {"workload": f"Othello 8x8, {args.traversals} UCT iters/move, {args.concurrent} concurrent games/GPU, "
+                                   f"{games} games/GPU/step, batch 8/queue 4, D4, Dirichlet(0.25,0.3)",
+                       "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32 via LibTorch-ROCm" if model_path else args.model),
+                       "parallelism": f"game-sharded x{world}, RCCL gather of records" if world > 1 else "1 GPU"},
+            "expansions_per_sec": d["expansions"] * world / elapsed,
+            "traversals_per_sec": d["traversals"] * world / elapsed,
+            "nn_evals_per_sec": d["nn_evals"] * world / elapsed,
+            "plies_per_game": d["plies"] / max(1, d["games"]),
+            "search_shape": shape,
+            "rank0": {"kernel_ms": d["kernel_ms"], "nn_ms": d["nn_ms"], "kernel_launches": d["kernel_launches"],
+                      "rounds": d["rounds"], "hbm_gib": st1["hbm_bytes"] / 2**30,
+                      "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"]},
+        }
+        if not args.no_profile and d["kernel_ms"] > 0:
+            achieved = d["traversals"] * bpt / (d["kernel_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "step_kernel<Othello> (select/expand/backup/re-root)",
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "bytes_per_traversal": bpt,
+                               "avg_launch_ms": d["kernel_ms"] / max(1, d["kernel_launches"]),
+                               "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"])}
+        if world == 1 and not args.no_cpu_baseline:
+            mp_model = model_path
+            if mp_model is None:
+                mp_model = trace_to_file(make_network("othello", args.blocks, args.channels, seed=0),
+                                         os.path.join(tmpdir, "traced_cpu.pt"), "othello")
+            try:
+                out["cpu_baseline"] = cpu_baseline(mp_model, args.traversals)
+            except Exception as exc:  # the baseline is reported, never the target: do not lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "reference",
+                                       "sample": f"failed: {exc}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -410,6 +410,7 @@ SPRL_DEV bool compact_arena(const EngineParams& P, Game& g) {
     }
     got = wv::bcast_u32(got, 0);
     if (got == 0xFFFFFFFFu) { raise_error(P, g, ERR_NO_SPARE); return false; }
+    wv::agent_acquire();                      // the arena's previous owner may have run on another XCD
     uint8_t* from = g.abase;
     uint8_t* to = P.arenas + (size_t)got * (size_t)P.node_cap * SPRL_NODE_BYTES;
     copy_node(node_at(from, g.root), node_at(to, 0));
@@ -440,6 +441,7 @@ SPRL_DEV bool compact_arena(const EngineParams& P, Game& g) {
         wv::wave_fence();
         ++scan;
     }
+    wv::agent_release();                      // no dirty line of the old arena may outlive its release
     if (l == 0) wv::atomic_store_u32(&P.arena_used[g.arena], 0u);
     g.arena = got;
     g.abase = to;

@@ -75,6 +75,8 @@ static inline void atomic_store_u32(uint32_t* p, uint32_t v) { __atomic_store_n(
 // wave-uniform location and later stores to it needs one of these between the load and the store
 static inline void sync() { (void)emu::exchange(0, __LINE__); }
 static inline void wave_fence() { sync(); }
+static inline void agent_release() {}
+static inline void agent_acquire() {}
 }  // namespace wv
 
 #else
@@ -115,6 +117,18 @@ SPRL_DEV uint32_t atomic_cas_u32(uint32_t* p, uint32_t expect, uint32_t desired)
 SPRL_DEV void atomic_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // make this wave's completed global stores visible to its own other lanes (same CU, same L1)
 SPRL_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+// Ownership of a memory region moving between wavefronts that may sit on different XCDs: the per-XCD L2s are
+// write-back and not coherent with each other, so the old owner writes its dirty lines back (buffer_wbl2) before
+// publishing the hand-off and the new owner invalidates its L1 after winning it (MI355X_MICROARCH.md,
+// "Workgroup dispatch, XCD placement & inter-workgroup visibility").
+SPRL_DEV void agent_release() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+SPRL_DEV void agent_acquire() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // lanes of a wavefront execute in lockstep: nothing to do on hardware (see the emulator's sync())
 SPRL_DEV void sync() { __builtin_amdgcn_wave_barrier(); }
 }  // namespace wv
