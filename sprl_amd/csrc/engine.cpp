@@ -221,12 +221,13 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.rounds = 1;
 
     const size_t arenas = (size_t)(P.num_slots + P.num_spare);
-    const size_t nq = (size_t)P.num_slots * SPRL_MAXQ;
+    const size_t nq = (size_t)P.num_slots * (size_t)P.max_queue;   // dense network batch: slot-major, queue-minor
+    const size_t npaths = (size_t)P.num_slots * SPRL_MAXQ;
     bool ok = true;
     ok = ok && (P.arenas = (uint8_t*)dev_alloc(e, arenas * (size_t)P.node_cap * SPRL_NODE_BYTES));
     ok = ok && (P.arena_used = (uint32_t*)dev_alloc(e, arenas * sizeof(uint32_t)));
     ok = ok && (P.ctl = (GameCtl*)dev_alloc(e, (size_t)P.num_slots * sizeof(GameCtl)));
-    ok = ok && (P.paths = (uint32_t*)dev_alloc(e, nq * (size_t)P.max_depth * sizeof(uint32_t)));
+    ok = ok && (P.paths = (uint32_t*)dev_alloc(e, npaths * (size_t)P.max_depth * sizeof(uint32_t)));
     ok = ok && (P.nn_in = (float*)dev_alloc(e, nq * 3 * (size_t)e->g.cells * sizeof(float)));
     ok = ok && (e->nn_logits = (float*)dev_alloc(e, nq * (size_t)e->g.A * sizeof(float)));
     ok = ok && (e->nn_value = (float*)dev_alloc(e, nq * sizeof(float)));
@@ -337,7 +338,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
     const bool net = e->eval_kind == SPRL_EVAL_NETWORK;
     const int launches = net ? rounds : 1;
     P.rounds = net ? 1 : rounds;
-    const int batch = P.num_slots * SPRL_MAXQ;
+    const int batch = P.num_slots * P.max_queue;
     for (int r = 0; r < launches; ++r) {
         be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
         void* k0 = e->cfg.profile ? be::mark() : nullptr;

@@ -251,7 +251,7 @@ SPRL_DEV void finish_leaves(const EngineParams& P, Game& g, int slot, GameCtl* c
         uint8_t* np = node_at(g.abase, leaf);
         NodeHdr h = load_hdr(np);
         if (!(h.flags & F_EVAL)) {
-            evaluate_leaf<G>(P, g, np, h, sym, slot * SPRL_MAXQ + q);
+            evaluate_leaf<G>(P, g, np, h, sym, slot * P.max_queue + q);
         } else {
             g.st.dup_hits++;
         }
@@ -382,7 +382,7 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         ctl->leaf_sym[q] = (uint32_t)sym;
         if (P.eval_kind == EVAL_NETWORK) {
             NodeHdr lh = load_hdr(node_at(g.abase, ctl->leaf_node[q]));
-            encode_leaf<G>(P, lh, sym, slot * SPRL_MAXQ + q);
+            encode_leaf<G>(P, lh, sym, slot * P.max_queue + q);
         }
     }
     g.st.nn_evals += (unsigned long long)g.n_leaves;

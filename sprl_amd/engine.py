@@ -59,6 +59,23 @@ class Stats(C.Structure):
 FORWARD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
 
 _libs = {}
+_hip_runtime = None
+
+
+def _preload_torch_hip_runtime():
+    """The engine and the LibTorch-ROCm evaluator must share ONE HIP/HSA runtime in the process.  The torch wheel
+    bundles its own (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7); loading it first makes the dynamic
+    linker satisfy libsprl_amd.so's libamdhip64.so.7 dependency with that same copy instead of /opt/rocm's."""
+    global _hip_runtime
+    if _hip_runtime is not None:
+        return
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        _hip_runtime = False
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    _hip_runtime = C.CDLL(cand, mode=C.RTLD_GLOBAL) if os.path.exists(cand) else False
 
 
 def load_library(path=None):
@@ -69,6 +86,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise SprlError(-4, f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _preload_torch_hip_runtime()
     L = C.CDLL(path)
     L.sprl_last_error.restype = C.c_char_p
     L.sprl_config_default.argtypes = [C.c_int32, C.POINTER(Config)]
