@@ -155,35 +155,13 @@ def main():
         torch.cuda.synchronize()
 
     def gather_records(rec):
-        """RCCL gather of the compact finished-game records to rank 0: equal-sized padded shards."""
+        """RCCL gather of the compact finished-game records to rank 0."""
         if dist is None:
             return rec.total_plies
-        import numpy as np
-        cap = games * cfg_max_plies
-        buf = np.zeros((cap, 16 + 1 + rec.actions * 4), np.uint8)
-        n = rec.total_plies
-        packed = np.zeros((n, 64), np.int8)
-        packed[:, :rec.cells] = rec.boards
-        buf[:n, :16] = np.packbits((packed[:, :64] == 0), axis=1, bitorder="little").view(np.uint8).reshape(n, 8).repeat(1, axis=1).tolist() if False else 0
-        # boards as two bit-planes (player ZERO / ONE), mover, pdf
-        b0 = np.packbits(packed == 0, axis=1, bitorder="little")
-        b1 = np.packbits(packed == 1, axis=1, bitorder="little")
-        buf[:n, 0:8] = b0
-        buf[:n, 8:16] = b1
-        buf[:n, 16] = rec.movers.view(np.uint8)
-        buf[:n, 17:] = rec.pdfs.view(np.uint8).reshape(n, -1)
-        t = torch.from_numpy(buf).cuda()
-        meta = torch.tensor([n, rec.num_games], device="cuda", dtype=torch.int64)
-        metas = [torch.zeros_like(meta) for _ in range(world)] if rank == 0 else None
-        outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-        dist.gather(meta, metas, dst=0)
-        dist.gather(t, outs, dst=0)
+        from sprl_amd.distributed import gather_records as _gather
+        shards = _gather(rec, dist, device=torch.device("cuda", local_rank))
         torch.cuda.synchronize()
-        if rank == 0:
-            return int(sum(int(m[0]) for m in metas))
-        return n
-
-    cfg_max_plies = 128
+        return sum(sh["total_plies"] for sh in shards) if shards is not None else rec.total_plies
 
     def one_step():
         eng.begin(games)

@@ -1,0 +1,176 @@
+"""GPU self-play worker honouring the reference workers' process + filesystem contract.
+
+Mirrors `OTHWorker <task_id> <num_tasks>` / `C4Worker` (cpp/src/OTHWorker.cpp:31-70, cpp/src/C4Worker.cpp) and
+`runWorker` (cpp/src/selfplay/GridWorker.hpp:84-198):
+
+* reads   data/models/<run>/traced_<run>_iteration_<i-1>.pt          (GridWorker.hpp:36-55; iteration 0 = built-in
+          initial evaluator, "random")
+* writes  data/games/<run>/<group>/<task_id>/<run>_iteration_<i>_{states,distributions,outcomes}.npy
+          (GridWorker.hpp:116,173-196; OTHWorker.cpp:44-49), group = task_id // (num_tasks // num_groups)
+* iteration 0 uses the init budgets, later iterations the steady-state ones (GridWorker.hpp:118-121; the reference's
+  shadowing bug Q2 is NOT reproduced: the steady-state values are the worker constants).
+
+One MI355X replaces many CPU tasks: `--cover K` makes this process play the games of task ids
+[task_id, task_id + K) concurrently on the GPU and write each task's files into that task's own directory, so the
+unmodified Python controller (scripts/othello_controller.py:66-125) sees exactly the files it polls for.
+Files appear atomically (temp + rename), outcomes last.
+"""
+import argparse
+import os
+import sys
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import engine as E
+
+MODEL_PATH_WAIT_INTERVAL = 30  # GridWorker.hpp:23
+
+
+@dataclass
+class WorkerConstants:
+    game: str
+    run_name: str
+    num_groups: int
+    num_worker_tasks: int
+    num_iters: int
+    init_games: int
+    init_traversals: int
+    init_max_batch: int
+    init_max_queue: int
+    games: int
+    traversals: int
+    max_batch: int
+    max_queue: int
+    dir_eps: float
+    dir_alpha: float
+
+
+# OTHWorker.cpp:12-32, C4Worker.cpp:11-30
+REFERENCE_WORKERS = {
+    "othello": WorkerConstants("othello", "orangutan_alpha", 4, 384, 50, 3, 131072, 1, 1, 3, 8192, 8, 4, 0.25, 0.3),
+    "connect_four": WorkerConstants("connect_four", "panda_gamma", 1, 1, 25, 10, 2048, 1, 1, 5, 512, 8, 4, 0.25, 0.5),
+}
+
+
+def model_path_for(iteration, run_name, root="."):
+    """waitModelPath's path scheme (GridWorker.hpp:35-43); iteration -1 -> "random"."""
+    if iteration == -1:
+        return "random"
+    return os.path.join(root, "data", "models", run_name, f"traced_{run_name}_iteration_{iteration}.pt")
+
+
+def wait_model_path(iteration, run_name, root=".", poll_seconds=MODEL_PATH_WAIT_INTERVAL, settle_seconds=5, log=print):
+    path = model_path_for(iteration, run_name, root)
+    if path == "random":
+        return path
+    while not os.path.exists(path):
+        log(f"Spinning on traced model from iteration {iteration}...")
+        time.sleep(poll_seconds)
+    time.sleep(settle_seconds)          # GridWorker.hpp:52
+    return path
+
+
+def save_dir_for(consts, task_id, root="."):
+    group = task_id // (consts.num_worker_tasks // consts.num_groups)       # OTHWorker.cpp:44
+    return os.path.join(root, "data", "games", consts.run_name, str(group), str(task_id))
+
+
+def split_records(rec, games_per_task):
+    """Slice a run's compact records into per-task (states, distributions, outcomes) in the reference's sample order."""
+    states, dists, outs = rec.expand()
+    nsym = rec.nsym if rec.use_symmetry else 1
+    offs = rec.ply_offset.astype(np.int64) * nsym
+    out = []
+    for t in range(rec.num_games // games_per_task):
+        a, b = offs[t * games_per_task], offs[(t + 1) * games_per_task]
+        out.append((states[a:b], dists[a:b], outs[a:b]))
+    return out
+
+
+def _write_npy_atomic(path, arr):
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        _write_npy_reference_header(f, arr)
+    os.replace(tmp, path)
+
+
+def _write_npy_reference_header(f, arr):
+    """utils/npy.hpp:430-476 byte-for-byte (numpy's own writer pads differently)."""
+    arr = np.ascontiguousarray(arr, np.float32)
+    shape = "(%d,)" % arr.shape[0] if arr.ndim == 1 else "(" + ", ".join(str(s) for s in arr.shape) + ")"
+    d = "{'descr': '<f4', 'fortran_order': False, 'shape': %s, }" % shape
+    length = 6 + 2 + 2 + len(d) + 1
+    pad = 16 - length % 16
+    hl = len(d) + pad + 1
+    f.write(b"\x93NUMPY\x01\x00" + bytes([hl & 0xFF, hl >> 8]) + d.encode() + b" " * pad + b"\n")
+    f.write(arr.tobytes())
+
+
+def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, concurrent_games=None, lib=None,
+               model_for_iteration=None, log=print, device=0):
+    """The worker loop (GridWorker.hpp:111-197) for task ids [task_id, task_id + cover)."""
+    lib = lib or E.load_library()
+    num_iters = consts.num_iters if num_iters is None else num_iters
+    seed = int(time.time_ns() & 0x7FFFFFFFFFFF) | 1 if seed is None else seed   # reference: random_device (Q3)
+    dirs = [save_dir_for(consts, task_id + k, root) for k in range(cover)]
+    for d in dirs:
+        existed = os.path.isdir(d)
+        os.makedirs(d, exist_ok=True)
+        log(("Directory already exists: " if existed else "Created directory: ") + d)
+    next_stream = 1
+    for it in range(num_iters):
+        log(f"Starting iteration {it}...")
+        model = (model_for_iteration(it) if model_for_iteration else wait_model_path(it - 1, consts.run_name, root, log=log))
+        games = consts.init_games if it == 0 else consts.games
+        trav = consts.init_traversals if it == 0 else consts.traversals
+        mb = consts.init_max_batch if it == 0 else consts.max_batch
+        mq = consts.init_max_queue if it == 0 else consts.max_queue
+        total = games * cover
+        cfg = E.default_config(consts.game, lib, device=device, concurrent_games=min(concurrent_games or total, total),
+                               num_traversals=trav, max_batch=mb, max_queue=mq, dir_eps=consts.dir_eps,
+                               dir_alpha=consts.dir_alpha, seed=seed, stream_base=next_stream)
+        next_stream += total
+        eng = E.Engine(cfg, lib)
+        log("Using initial network..." if model == "random" else "Using traced PyTorch network...")
+        eng.set_model(model)
+        rec = eng.run(total)
+        for k, (st, di, ou) in enumerate(split_records(rec, games)):
+            prefix = os.path.join(dirs[k], f"{consts.run_name}_iteration_{it}")
+            _write_npy_atomic(prefix + "_states.npy", st)
+            _write_npy_atomic(prefix + "_distributions.npy", di)
+            _write_npy_atomic(prefix + "_outcomes.npy", ou)       # last: the controller waits for all three
+        log(f"{total} games played, {rec.num_samples} states collected.")
+        rec.close()
+        eng.close()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("game", choices=sorted(REFERENCE_WORKERS))
+    ap.add_argument("task_id", type=int)
+    ap.add_argument("num_tasks", type=int)
+    ap.add_argument("--cover", type=int, default=1, help="number of consecutive task ids this GPU stands in for")
+    ap.add_argument("--run-name")
+    ap.add_argument("--num-iters", type=int)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--seed", type=int)
+    try:
+        args = ap.parse_args(argv)
+    except SystemExit:
+        print("Usage: python -m sprl_amd.worker <game> <task_id> <num_tasks>", file=sys.stderr)   # OTHWorker.cpp:34-37
+        return 1
+    consts = REFERENCE_WORKERS[args.game]
+    if args.num_tasks != consts.num_worker_tasks:
+        print(f"num_tasks must be {consts.num_worker_tasks} (OTHWorker.cpp:42)", file=sys.stderr)
+        return 1
+    if args.run_name:
+        consts = WorkerConstants(**{**consts.__dict__, "run_name": args.run_name})
+    print(f"Task {args.task_id} of {args.num_tasks}, covering {args.cover} task(s).")
+    run_worker(consts, args.task_id, cover=args.cover, num_iters=args.num_iters, device=args.device, seed=args.seed)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
