@@ -15,9 +15,11 @@
 // lane with IEEE fp32 ops in the reference's order (UCTNode.hpp:200,210,236; no FMA contraction), the arg-max
 // is a wave butterfly, the tie set is a ballot, and the tie is broken with the reference's UniformInt draw.
 //
-// Coherence rule used throughout: an address is always written by the lane(s) that later read it (row element
-// a by lane a, header fields by all lanes with a uniform value), so intra-wave RAW through global memory
-// is always same-lane program order; the one exception (arena compaction) is followed by a fence.
+// Coherence rule: a tree is touched by exactly one wavefront, whose vector memory operations are issued and
+// performed in program order through one L1, so read-after-write inside the wave needs no cache maintenance.
+// Most addresses are written by the lane(s) that later read them (row element a by lane a, header fields by
+// all lanes with a uniform value); the cross-lane cases (backup scatter, arena compaction) are followed by a
+// workgroup-scope fence (= s_waitcnt vmcnt(0)).  Arenas that change owner cross XCDs: agent-scope release/acquire.
 #ifndef SPRL_STEP_KERNEL_H
 #define SPRL_STEP_KERNEL_H
 
@@ -38,6 +40,16 @@ SPRL_DEV float* rowW(uint8_t* n) { return (float*)(n + 256); }
 SPRL_DEV float* rowP(uint8_t* n) { return (float*)(n + 512); }
 SPRL_DEV uint16_t* rowC(uint8_t* n) { return (uint16_t*)(n + 768); }
 SPRL_DEV NodeHdr* hdr_of(uint8_t* n) { return (NodeHdr*)(n + 896); }
+// header + this lane's row elements in one batch of loads (the rows of a non-active node are never used)
+SPRL_DEV void load_node(uint8_t* np, NodeHdr& h, float& n, float& w, float& p, uint32_t& ch) {
+    const int l = wv::lane();
+    h = *hdr_of(np);
+    n = rowN(np)[l];
+    w = rowW(np)[l];
+    p = rowP(np)[l];
+    ch = rowC(np)[l];
+    wv::sync();
+}
 // wave-uniform copy of a node header; every lane has loaded it before any lane may go on to modify it
 SPRL_DEV NodeHdr load_hdr(uint8_t* n) {
     NodeHdr h = *hdr_of(n);
@@ -140,25 +152,28 @@ SPRL_DEV void expand_node(const EngineParams& P, Game& g, uint8_t* np, const Nod
 // ---------------------------------------------------------------------------------------------------
 template <class G>
 SPRL_DEV void backup_path(Game& g, uint32_t my_entry0, uint32_t my_entry1, int depth, int leaf_player, float value) {
+    // Lane j owns path edge j (and j + 64): all W loads go out together, then all stores — two memory round
+    // trips per backup instead of one per level.  The edges of one path are distinct addresses.
     const int l = wv::lane();
+    wv::sync();         // (emulator) the descent's own stores to these edges precede the read-modify-write below
     const float est = -value * (leaf_player == 0 ? 1.0f : -1.0f);
     g.rootW += 1.0f + est * (g.root_player == 0 ? 1.0f : -1.0f);
-    for (int j = 0; j < depth; ++j) {
-        uint32_t e = j < 64 ? wv::bcast_u32(my_entry0, j) : wv::bcast_u32(my_entry1, j - 64);
-        uint32_t node = e >> 8;
-        int a = (int)(e & 0xffu);
-        int child_player = (int)(g.root_player ^ ((uint32_t)(j + 1) & 1u));
-        float add = 1.0f + est * (child_player == 0 ? 1.0f : -1.0f);
-        uint8_t* np = node_at(g.abase, node);
-        if (G::HAS_PASS && a == SPRL_PASS) {
-            NodeHdr* h = hdr_of(np);
-            const float w = h->passW;
-            wv::sync();
-            h->passW = w + add;
-        } else if (l == a) {
-            rowW(np)[l] = rowW(np)[l] + add;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int j = l + 64 * half;
+        if (half == 1 && depth <= 64) break;
+        const uint32_t e = half == 0 ? my_entry0 : my_entry1;
+        if (j < depth) {
+            const uint32_t node = e >> 8;
+            const int a = (int)(e & 0xffu);
+            const int child_player = (int)(g.root_player ^ ((uint32_t)(j + 1) & 1u));
+            const float add = 1.0f + est * (child_player == 0 ? 1.0f : -1.0f);
+            uint8_t* np = node_at(g.abase, node);
+            float* wp = (G::HAS_PASS && a == SPRL_PASS) ? &hdr_of(np)->passW : &rowW(np)[a];
+            *wp = *wp + add;
         }
     }
+    wv::wave_fence();   // edges were updated by lane j, they are read back by lane `action` / as header fields
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -279,11 +294,13 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         g.rootN += 1.0f;                      // virtual loss on the decision node itself (Q5/Q6)
         g.rootW -= 1.0f;
         int depth = 0;
-        NodeHdr h = load_hdr(node_at(g.abase, cur));
+        // header and the four rows of a node are fetched together: one memory round trip per level
+        NodeHdr h;
+        float n, w, p;
+        uint32_t ch;
+        load_node(node_at(g.abase, cur), h, n, w, p, ch);
         while (h.exp_epoch == g.epoch && !(h.flags & F_TERMINAL)) {
             uint8_t* np = node_at(g.abase, cur);
-            float n = rowN(np)[l], w = rowW(np)[l], p = rowP(np)[l];
-            uint32_t ch = rowC(np)[l];
             int a;
             if (G::HAS_PASS && h.legal == 0) {             // pass is the only legal action (mask[64] only)
                 (void)rng_uniform_int(g.rng, 1u);           // bestAction still draws (UCTNode.hpp:250)
@@ -346,7 +363,7 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
                 h.flags = (uint8_t)((cs.terminal ? F_TERMINAL : 0) | (cs.pass_legal ? F_PASS : 0));
                 break;
             }
-            h = load_hdr(node_at(g.abase, cur));
+            load_node(node_at(g.abase, cur), h, n, w, p, ch);
         }
         // ---- leaf handling (UCTTree.hpp:87-110) ----
         if (h.flags & F_TERMINAL) {
