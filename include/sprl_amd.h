@@ -109,7 +109,7 @@ void sprl_records_free(sprl_records* r);
 typedef struct sprl_stats {
     int64_t games, plies, traversals, levels, expansions, nn_evals, terminal_hits, gray_hits, dup_hits,
         nodes_created, compactions, max_nodes_in_arena;
-    int64_t rounds, kernel_launches, nn_batches;
+    int64_t rounds, kernel_launches, nn_batches, nn_rows;   /* nn_rows = rows evaluated by the network incl. bucket padding */
     double seconds_total;      /* wall time inside run/step */
     double kernel_ms;          /* sum of tree-kernel durations (HIP events; profile=1) */
     double nn_ms;              /* sum of network forward durations (HIP events; profile=1) */

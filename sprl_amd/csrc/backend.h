@@ -21,6 +21,9 @@ int dmemset(void* dst, int v, size_t n);
 int sync();
 // one 64-lane wavefront per game slot, on the null stream
 int launch_step(int game, const EngineParams& P);
+// leaf_count -> leaf_offset (exclusive scan, slot order) + counters->leaf_total, then gather the queued leaves'
+// planes from the sparse staging into the dense network batch
+int launch_compact(const EngineParams& P, int floats_per_leaf);
 // event pairs on the null stream (profile mode); returns milliseconds between the two marks
 void* mark();
 double elapsed_ms(void* a, void* b);   // synchronises on b

@@ -26,6 +26,47 @@ __global__ void __launch_bounds__(64) step_kernel(EngineParams P) {
     if (slot < P.num_slots) sprl::step_game<G>(P, slot, lds_path);
 }
 
+// Exclusive scan of the per-slot leaf counts (slot order => the dense batch order is deterministic).
+// One 1024-thread workgroup: each thread owns a contiguous chunk of slots, chunk totals are scanned in LDS.
+__global__ void __launch_bounds__(1024) leaf_scan_kernel(const uint32_t* count, uint32_t* offset, Counters* counters, int n) {
+    __shared__ uint32_t part[1024];
+    const int t = (int)threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk, hi = min(n, lo + chunk);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += count[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int i = lo; i < hi; ++i) {
+        offset[i] = run;
+        run += count[i];
+    }
+    if (t == 1023) counters->leaf_total = part[1023];
+}
+
+// One wavefront per slot copies its <= max_queue leaves (16 B per lane per step) to their dense rows.
+__global__ void __launch_bounds__(64) leaf_gather_kernel(EngineParams P, int floats_per_leaf) {
+    const int slot = (int)blockIdx.x;
+    const uint32_t cnt = P.leaf_count[slot];
+    if (cnt == 0) return;
+    const uint32_t off = P.leaf_offset[slot];
+    const int vec = floats_per_leaf / 4;
+    for (uint32_t q = 0; q < cnt; ++q) {
+        const float4* src = (const float4*)(P.nn_in + ((size_t)slot * P.max_queue + q) * floats_per_leaf);
+        float4* dst = (float4*)(P.nn_dense + (size_t)(off + q) * floats_per_leaf);
+        for (int i = (int)threadIdx.x; i < vec; i += 64) dst[i] = src[i];
+        for (int i = vec * 4 + (int)threadIdx.x; i < floats_per_leaf; i += 64)
+            P.nn_dense[(size_t)(off + q) * floats_per_leaf + i] = P.nn_in[((size_t)slot * P.max_queue + q) * floats_per_leaf + i];
+    }
+}
+
 }  // namespace
 
 namespace be {
@@ -85,6 +126,12 @@ int launch_step(int game, const EngineParams& P) {
     if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(step_kernel<Othello>, grid, block, 0, 0, P);
     else hipLaunchKernelGGL(step_kernel<ConnectFour>, grid, block, 0, 0, P);
     return ok(hipGetLastError(), "step_kernel launch") ? 0 : -1;
+}
+
+int launch_compact(const EngineParams& P, int floats_per_leaf) {
+    hipLaunchKernelGGL(leaf_scan_kernel, dim3(1), dim3(1024), 0, 0, P.leaf_count, P.leaf_offset, P.counters, P.num_slots);
+    hipLaunchKernelGGL(leaf_gather_kernel, dim3((unsigned)P.num_slots), dim3(64), 0, 0, P, floats_per_leaf);
+    return ok(hipGetLastError(), "leaf compaction launch") ? 0 : -1;
 }
 
 void* mark() {

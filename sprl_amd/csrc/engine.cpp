@@ -79,7 +79,8 @@ struct sprl_engine {
     float* nn_logits = nullptr;
     float* nn_value = nullptr;
     // accounting
-    int64_t rounds = 0, launches = 0, nn_batches = 0;
+    int64_t rounds = 0, launches = 0, nn_batches = 0, nn_rows = 0;
+    int nn_bucket = 1024;
     double seconds = 0.0, kernel_ms = 0.0, nn_ms = 0.0;
     std::vector<void*> marks;  // k0,k1,(n0,n1) per round, resolved lazily
     std::vector<int> mark_kind;
@@ -229,6 +230,9 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     ok = ok && (P.ctl = (GameCtl*)dev_alloc(e, (size_t)P.num_slots * sizeof(GameCtl)));
     ok = ok && (P.paths = (uint32_t*)dev_alloc(e, npaths * (size_t)P.max_depth * sizeof(uint32_t)));
     ok = ok && (P.nn_in = (float*)dev_alloc(e, nq * 3 * (size_t)e->g.cells * sizeof(float)));
+    ok = ok && (P.nn_dense = (float*)dev_alloc(e, nq * 3 * (size_t)e->g.cells * sizeof(float)));
+    ok = ok && (P.leaf_count = (uint32_t*)dev_alloc(e, (size_t)P.num_slots * sizeof(uint32_t)));
+    ok = ok && (P.leaf_offset = (uint32_t*)dev_alloc(e, (size_t)P.num_slots * sizeof(uint32_t)));
     ok = ok && (e->nn_logits = (float*)dev_alloc(e, nq * (size_t)e->g.A * sizeof(float)));
     ok = ok && (e->nn_value = (float*)dev_alloc(e, nq * sizeof(float)));
     ok = ok && (P.counters = (Counters*)dev_alloc(e, sizeof(Counters)));
@@ -240,6 +244,9 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.nn_logits = e->nn_logits;
     P.nn_value = e->nn_value;
     be::dmemset(P.nn_in, 0, nq * 3 * (size_t)e->g.cells * sizeof(float));
+    be::dmemset(P.nn_dense, 0, nq * 3 * (size_t)e->g.cells * sizeof(float));
+    be::dmemset(P.leaf_count, 0, (size_t)P.num_slots * sizeof(uint32_t));
+    be::dmemset(P.leaf_offset, 0, (size_t)P.num_slots * sizeof(uint32_t));
     be::dmemset(e->nn_logits, 0, nq * (size_t)e->g.A * sizeof(float));
     be::dmemset(e->nn_value, 0, nq * sizeof(float));
     be::sync();
@@ -276,6 +283,20 @@ int sprl_engine_set_model(sprl_engine* e, const char* model) {
     e->torch_model = m;
     e->forward_cb = nullptr;
     e->eval_kind = SPRL_EVAL_NETWORK;
+    // Touch every batch shape the round loop can produce (multiples of the bucket) once, so that the convolution
+    // library's per-shape solver selection happens here and not inside a self-play run.
+    const int max_rows = e->P.num_slots * e->P.max_queue;
+    int last = 0;
+    for (int rows = e->nn_bucket;; rows += e->nn_bucket) {
+        int b = rows < max_rows ? rows : max_rows;
+        if (b == last) break;
+        last = b;
+        if (e->torch.forward(m, e->P.nn_dense, b, 3, e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, err,
+                             (int)sizeof(err)) != 0)
+            return fail(SPRL_E_MODEL, std::string("network warm-up forward failed: ") + err);
+        if (b == max_rows) break;
+    }
+    be::sync();
     return 0;
 }
 
@@ -321,6 +342,8 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
     rc |= be::h2d(P.ctl, ctl.data(), ctl.size() * sizeof(GameCtl));
     rc |= be::h2d(P.arena_used, used.data(), used.size() * sizeof(uint32_t));
     rc |= be::h2d(P.counters, &c, sizeof(c));
+    rc |= be::dmemset(P.leaf_count, 0, (size_t)P.num_slots * sizeof(uint32_t));
+    rc |= be::dmemset(P.leaf_offset, 0, (size_t)P.num_slots * sizeof(uint32_t));
     rc |= be::dmemset(P.rec_nplies, 0, (size_t)num_games * sizeof(int32_t));
     rc |= be::dmemset(P.rec_pdf, 0, np * (size_t)e->g.A * sizeof(float));
     rc |= be::sync();
@@ -338,7 +361,10 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
     const bool net = e->eval_kind == SPRL_EVAL_NETWORK;
     const int launches = net ? rounds : 1;
     P.rounds = net ? 1 : rounds;
-    const int batch = P.num_slots * P.max_queue;
+    const int max_batch_rows = P.num_slots * P.max_queue;
+    const int floats_per_leaf = 3 * e->g.cells;
+    Counters c;
+    memset(&c, 0, sizeof(c));
     for (int r = 0; r < launches; ++r) {
         be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
         void* k0 = e->cfg.profile ? be::mark() : nullptr;
@@ -350,32 +376,43 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
         }
         e->launches++;
         if (net) {
-            void* n0 = e->cfg.profile ? be::mark() : nullptr;
-            int rc;
-            char err[512] = { 0 };
-            if (e->forward_cb) {
-                rc = e->forward_cb(e->forward_user, P.nn_in, batch, e->nn_logits, e->nn_value);
-                if (rc) snprintf(err, sizeof(err), "forward callback returned %d", rc);
-            } else {
-                rc = e->torch.forward(e->torch_model, P.nn_in, batch, 3, e->g.rows, e->g.cols, e->nn_logits,
-                                      e->g.A, e->nn_value, err, (int)sizeof(err));
+            // dense batch: only the leaves that were really queued, slot-major (deterministic), in buckets of
+            // `bucket` rows so the convolution library sees a handful of shapes
+            if (be::launch_compact(P, floats_per_leaf) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+            if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+            if (c.error != ERR_NONE) break;
+            const int bucket = e->nn_bucket;
+            int batch = (int)((c.leaf_total + (uint32_t)bucket - 1) / (uint32_t)bucket) * bucket;
+            if (batch > max_batch_rows) batch = max_batch_rows;
+            if (c.leaf_total > 0) {
+                void* n0 = e->cfg.profile ? be::mark() : nullptr;
+                int rc;
+                char err[512] = { 0 };
+                if (e->forward_cb) {
+                    rc = e->forward_cb(e->forward_user, P.nn_dense, batch, e->nn_logits, e->nn_value);
+                    if (rc) snprintf(err, sizeof(err), "forward callback returned %d", rc);
+                } else {
+                    rc = e->torch.forward(e->torch_model, P.nn_dense, batch, 3, e->g.rows, e->g.cols, e->nn_logits,
+                                          e->g.A, e->nn_value, err, (int)sizeof(err));
+                }
+                if (rc) {
+                    e->running = false;
+                    return fail(SPRL_E_MODEL, std::string("network forward failed: ") + err);
+                }
+                if (e->cfg.profile) {
+                    e->marks.push_back(n0);
+                    e->marks.push_back(be::mark());
+                    e->mark_kind.push_back(1);
+                }
+                e->nn_batches++;
+                e->nn_rows += batch;
             }
-            if (rc) {
-                e->running = false;
-                return fail(SPRL_E_MODEL, std::string("network forward failed: ") + err);
-            }
-            if (e->cfg.profile) {
-                e->marks.push_back(n0);
-                e->marks.push_back(be::mark());
-                e->mark_kind.push_back(1);
-            }
-            e->nn_batches++;
+            if (c.games_done >= (uint32_t)e->num_games && c.active_slots == 0 && c.leaf_total == 0) break;
         }
         if (e->marks.size() >= 4096) resolve_marks(e);
     }
     e->rounds += rounds;
-    Counters c;
-    if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+    if (!net && (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0)) return fail(SPRL_E_DEVICE, be::last_error());
     e->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (games_done) *games_done = (int32_t)c.games_done;
     if (active_slots) *active_slots = (int32_t)c.active_slots;
@@ -490,6 +527,7 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
     out->rounds = e->rounds;
     out->kernel_launches = e->launches;
     out->nn_batches = e->nn_batches;
+    out->nn_rows = e->nn_rows;
     out->seconds_total = e->seconds;
     out->kernel_ms = e->kernel_ms;
     out->nn_ms = e->nn_ms;

@@ -11,7 +11,8 @@
 //            child[64] u16, 64 B header (bitboards, legal mask, cached value, pass-edge stats, flags).
 //            The cached network policy lives in the P row (it is only ever consumed through expand()).
 //   paths    [slots][MAXQ][MAX_DEPTH] u32 (node<<8 | action) for leaves waiting on the network.
-//   nn_in    [slots*MAXQ][2H+1][R][C] f32, nn_logits [slots*MAXQ][A], nn_value [slots*MAXQ]
+//   nn_in    [slots*maxQueue][2H+1][R][C] f32 sparse staging -> nn_dense (slot-major compaction of the real
+//            leaves, deterministic order) -> nn_logits [leaves][A], nn_value [leaves]
 //   records  compact per ply: 2 x u64 bitboards, mover, tempered pdf f32[A]; winner per game.
 #ifndef SPRL_ENGINE_TYPES_H
 #define SPRL_ENGINE_TYPES_H
@@ -80,7 +81,8 @@ struct Counters {
     uint32_t error;         // first ERR_* raised by any game
     uint32_t error_game;
     uint32_t active_slots;  // slots still holding an unfinished game after the last step
-    uint32_t pad[3];
+    uint32_t leaf_total;    // leaves queued for the network by the last step (dense batch size)
+    uint32_t pad[2];
 };
 
 struct EngineParams {
@@ -97,7 +99,10 @@ struct EngineParams {
     uint32_t* arena_used;   // [num_slots + num_spare] 0 free / 1 used
     GameCtl* ctl;
     uint32_t* paths;
-    float* nn_in;
+    float* nn_in;           // sparse staging [slot][max_queue][planes][cells], written by the tree kernel
+    uint32_t* leaf_count;   // [num_slots] leaves queued by each slot in the last step
+    uint32_t* leaf_offset;  // [num_slots] exclusive prefix sum of leaf_count = row of the slot's first leaf
+    float* nn_dense;        // dense network batch [leaf_total (rounded up)][planes][cells]
     const float* nn_logits;
     const float* nn_value;
     uint64_t* rec_boards;

@@ -259,6 +259,7 @@ SPRL_DEV void encode_leaf(const EngineParams& P, const NodeHdr& h, int sym, int 
 template <class G>
 SPRL_DEV void finish_leaves(const EngineParams& P, Game& g, int slot, GameCtl* ctl) {
     const int l = wv::lane();
+    const int nn_base = (int)P.leaf_offset[slot];     // row of this slot's first leaf in the dense network batch
     for (int q = 0; q < g.n_leaves; ++q) {
         const uint32_t leaf = ctl->leaf_node[q];
         const int depth = (int)ctl->leaf_depth[q];
@@ -266,7 +267,7 @@ SPRL_DEV void finish_leaves(const EngineParams& P, Game& g, int slot, GameCtl* c
         uint8_t* np = node_at(g.abase, leaf);
         NodeHdr h = load_hdr(np);
         if (!(h.flags & F_EVAL)) {
-            evaluate_leaf<G>(P, g, np, h, sym, slot * P.max_queue + q);
+            evaluate_leaf<G>(P, g, np, h, sym, nn_base + q);
         } else {
             g.st.dup_hits++;
         }
@@ -649,6 +650,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
     ctl->n_leaves = g.n_leaves;
     ctl->root_player = g.root_player;
     ctl->stats = g.st;
+    P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
     if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
 }
 

@@ -49,7 +49,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "games", "plies", "traversals", "levels", "expansions", "nn_evals", "terminal_hits", "gray_hits",
         "dup_hits", "nodes_created", "compactions", "max_nodes_in_arena", "rounds", "kernel_launches",
-        "nn_batches")] + [("seconds_total", C.c_double), ("kernel_ms", C.c_double), ("nn_ms", C.c_double),
+        "nn_batches", "nn_rows")] + [("seconds_total", C.c_double), ("kernel_ms", C.c_double), ("nn_ms", C.c_double),
                           ("hbm_bytes", C.c_int64)]
 
     def as_dict(self):

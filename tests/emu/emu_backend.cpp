@@ -43,6 +43,18 @@ int launch_step(int game, const EngineParams& P) {
     else emu::launch(block_entry<ConnectFour>, &copy, P.num_slots);
     return 0;
 }
+int launch_compact(const EngineParams& P, int floats_per_leaf) {
+    uint32_t run = 0;
+    for (int s = 0; s < P.num_slots; ++s) {
+        P.leaf_offset[s] = run;
+        for (uint32_t q = 0; q < P.leaf_count[s]; ++q)
+            memcpy(P.nn_dense + (size_t)(run + q) * floats_per_leaf,
+                   P.nn_in + ((size_t)s * P.max_queue + q) * floats_per_leaf, (size_t)floats_per_leaf * sizeof(float));
+        run += P.leaf_count[s];
+    }
+    P.counters->leaf_total = run;
+    return 0;
+}
 void* mark() {
     auto* t = new std::chrono::steady_clock::time_point(std::chrono::steady_clock::now());
     return t;
