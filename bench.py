@@ -2,8 +2,7 @@
 """bench.py — self-play games/sec (+ UCT node-expansions/sec) on MI355X, Othello 8x8 @ 800 iters/move.
 
 A *step* is one self-play iteration in the reference's sense (runIteration, cpp/src/selfplay/SelfPlay.hpp:204-248):
-every GPU plays `--games` games (default 8192 = 2 x its 4096 resident game slots; a finished game's slot takes the
-next game from the queue) from the start position to the end,
+every GPU plays `--games` games (default = its 4096 resident game slots) from the start position to the end,
 with the reference worker's search constants (OTHWorker.cpp:24-28, constants.hpp:6-10), a random-init
 2-block x 64-channel policy/value CNN evaluated in fp32 through LibTorch-ROCm, D4 symmetrisation, Dirichlet
 noise, parent-Q init and sub-tree reuse, and emits the compact self-play records (gathered to rank 0 over RCCL
@@ -101,8 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--games", type=int, default=0,
-                    help="games per GPU per step (default: 2 x --concurrent, so finished games are replaced from the queue)")
+    ap.add_argument("--games", type=int, default=0, help="games per GPU per step (default: = --concurrent)")
     ap.add_argument("--concurrent", type=int, default=4096, help="resident game slots per GPU")
     ap.add_argument("--traversals", type=int, default=800)
     ap.add_argument("--model", default="cnn", choices=["cnn", "random", "heuristic"],
@@ -135,7 +133,7 @@ def main():
     from sprl_amd import engine as E
     from sprl_amd.network import make_network, trace_to_file
 
-    games = args.games or 2 * args.concurrent
+    games = args.games or args.concurrent
     lib = E.load_library()
     tmpdir = tempfile.mkdtemp(prefix="sprl_bench_")
     model_path = None
@@ -224,7 +222,8 @@ def main():
             "plies_per_game": d["plies"] / max(1, d["games"]),
             "search_shape": shape,
             "rank0": {"kernel_ms": d["kernel_ms"], "nn_ms": d["nn_ms"], "kernel_launches": d["kernel_launches"],
-                      "rounds": d["rounds"], "hbm_gib": st1["hbm_bytes"] / 2**30,
+                      "rounds": d["rounds"], "nn_batches": d["nn_batches"], "nn_rows": d["nn_rows"],
+                      "nn_fill": d["nn_evals"] / max(1, d["nn_rows"]), "hbm_gib": st1["hbm_bytes"] / 2**30,
                       "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"]},
         }
         if not args.no_profile and d["kernel_ms"] > 0:

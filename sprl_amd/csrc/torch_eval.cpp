@@ -5,6 +5,9 @@
 // writes as in GridNetwork.hpp:72-97,104-107).  The MFMA work of the whole engine lives inside this call
 // (MIOpen / hipBLASLt convolutions and GEMMs).  Kept in its own shared object so the core library has no
 // torch dependency; C ABI, plain pointers only.
+#include <torch/csrc/jit/api/module.h>
+#include <torch/csrc/jit/ir/ir.h>
+#include <torch/csrc/jit/passes/freeze_module.h>
 #include <torch/script.h>
 #include <torch/torch.h>
 
@@ -16,6 +19,38 @@ struct Model {
     torch::jit::Module module;
     int device = 0;
 };
+
+// After freezing, every convolution carries its bias as a constant and ATen applies it with a separate full-tensor
+// elementwise kernel (the convolution library does not add it).  Move the bias into an explicit broadcast add right
+// behind the convolution: the JIT fuser then folds it into the BatchNorm/ReLU kernel that follows, so each
+// convolution costs one elementwise pass over the activations instead of two.  Values are unchanged up to fp32
+// rounding order ((conv + b) then BN, exactly as before).
+int hoist_conv_bias(torch::jit::Module& module) {
+    using namespace torch::jit;
+    auto graph = module.get_method("forward").graph();
+    std::vector<Node*> convs;
+    for (Node* n : graph->nodes())
+        if (n->kind() == aten::_convolution || n->kind() == aten::conv2d) convs.push_back(n);
+    int moved = 0;
+    for (Node* n : convs) {
+        Value* bias = n->input(2);
+        auto iv = toIValue(bias);
+        if (!iv || !iv->isTensor()) continue;
+        at::Tensor b = iv->toTensor();
+        if (!b.defined() || b.dim() != 1) continue;
+        WithInsertPoint guard(n);               // constants go in front of the convolution
+        Value* none = graph->insertConstant(IValue());
+        Value* b4 = graph->insertConstant(b.reshape({ 1, -1, 1, 1 }).contiguous());
+        Value* one = graph->insertConstant(1);
+        Node* add = graph->create(aten::add, { n->output(), b4, one });
+        add->output()->setType(n->output()->type());
+        add->insertAfter(n);
+        n->output()->replaceAllUsesAfterNodeWith(add, add->output());
+        n->replaceInput(2, none);
+        ++moved;
+    }
+    return moved;
+}
 
 void put_err(char* err, int errlen, const std::string& msg) {
     if (err && errlen > 0) {
@@ -29,14 +64,25 @@ extern "C" {
 
 void* sprl_torch_load(const char* path, int device, char* err, int errlen) {
     try {
-        if (!torch::cuda::is_available()) {
+        // device < 0: host tensors — used only by the CPU unit test of the graph rewrite, never by the engine
+        if (device >= 0 && !torch::cuda::is_available()) {
             put_err(err, errlen, "LibTorch reports no ROCm device");
             return nullptr;
         }
         auto* m = new Model();
         m->device = device;
-        m->module = torch::jit::load(path, torch::Device(torch::kCUDA, (c10::DeviceIndex)device));
+        m->module = torch::jit::load(path, device >= 0 ? torch::Device(torch::kCUDA, (c10::DeviceIndex)device)
+                                                       : torch::Device(torch::kCPU));
         m->module.eval();                       // GridNetwork.hpp:67
+        if (!getenv("SPRL_TORCH_NO_REWRITE")) {
+            try {
+                torch::jit::Module frozen = torch::jit::freeze_module(m->module);
+                hoist_conv_bias(frozen);
+                m->module = frozen;
+            } catch (const std::exception&) {
+                // keep the module as loaded: the rewrite is an optimisation only
+            }
+        }
         return m;
     } catch (const std::exception& e) {
         put_err(err, errlen, e.what());
@@ -49,7 +95,9 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
     try {
         auto* m = static_cast<Model*>(handle);
         c10::InferenceMode guard;
-        auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, (c10::DeviceIndex)m->device);
+        auto opts = m->device >= 0
+                        ? torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, (c10::DeviceIndex)m->device)
+                        : torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCPU);
         auto in = torch::from_blob(const_cast<float*>(planes), { batch, nplanes, rows, cols }, opts);
         auto out = m->module.forward({ in }).toTuple();             // GridNetwork.hpp:99-102
         auto lo = out->elements()[0].toTensor();
