@@ -182,7 +182,8 @@ SPRL_DEV void backup_path(Game& g, uint32_t my_entry0, uint32_t my_entry1, int d
 // state was presented in; the mask is deliberately NOT symmetrised in MASK_REFERENCE mode.
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV void evaluate_leaf(const EngineParams& P, Game& g, uint8_t* np, NodeHdr& hc, int sym, int nn_slot) {
+SPRL_DEV void evaluate_leaf(const EngineParams& P, Game& g, uint8_t* np, NodeHdr& hc, int sym,
+                           float my_logit, float pass_logit, float nn_value) {
     const int l = wv::lane();
     NodeHdr* h = hdr_of(np);
     const uint64_t legal = hc.legal;
@@ -199,9 +200,8 @@ SPRL_DEV void evaluate_leaf(const EngineParams& P, Game& g, uint8_t* np, NodeHdr
     const int num_legal = wv::popc64(used) + (pass_legal ? 1 : 0);
     float pol, pass_pol = 0.0f, value = 0.0f;
     if (P.eval_kind == EVAL_NETWORK) {
-        const float* logits = P.nn_logits + (size_t)nn_slot * G::A;
-        float e = mine ? sprl_expf(logits[l]) : 0.0f;                       // GridNetwork.hpp:110-121
-        float e_pass = pass_legal ? sprl_expf(logits[G::A - 1]) : 0.0f;
+        float e = mine ? sprl_expf(my_logit) : 0.0f;                        // GridNetwork.hpp:110-121
+        float e_pass = pass_legal ? sprl_expf(pass_logit) : 0.0f;
         float sum = 0.0f;                                                   // GameActionDist::sum, index order
         for (uint64_t m = used; m; m &= m - 1) sum += wv::bcast_f32(e, wv::ctz64(m));
         if (pass_legal) sum += e_pass;
@@ -214,7 +214,7 @@ SPRL_DEV void evaluate_leaf(const EngineParams& P, Game& g, uint8_t* np, NodeHdr
             pol = e * inv;
             pass_pol = e_pass * inv;
         }
-        value = P.nn_value[nn_slot];
+        value = nn_value;
     } else {
         float uniform = 1.0f / (float)num_legal;                            // RandomNetwork.hpp:29-43
         pol = mine ? uniform : 0.0f;
@@ -265,16 +265,25 @@ SPRL_DEV void finish_leaves(const EngineParams& P, Game& g, int slot, GameCtl* c
         const int depth = (int)ctl->leaf_depth[q];
         const int sym = (int)ctl->leaf_sym[q];
         uint8_t* np = node_at(g.abase, leaf);
-        NodeHdr h = load_hdr(np);
+        // everything this leaf needs from memory is requested up front: one round trip
+        NodeHdr h = *hdr_of(np);
+        const uint32_t* path = P.paths + ((size_t)slot * SPRL_MAXQ + q) * P.max_depth;
+        const uint32_t e0 = l < depth ? path[l] : 0u;
+        const uint32_t e1 = 64 + l < depth ? path[64 + l] : 0u;
+        float my_logit = 0.0f, pass_logit = 0.0f, nn_value = 0.0f;
+        if (P.eval_kind == EVAL_NETWORK) {
+            const float* logits = P.nn_logits + (size_t)(nn_base + q) * G::A;
+            if (l < G::NA) my_logit = logits[l];
+            if (G::HAS_PASS) pass_logit = logits[G::A - 1];
+            nn_value = P.nn_value[nn_base + q];
+        }
+        wv::sync();
         if (!(h.flags & F_EVAL)) {
-            evaluate_leaf<G>(P, g, np, h, sym, nn_base + q);
+            evaluate_leaf<G>(P, g, np, h, sym, my_logit, pass_logit, nn_value);
         } else {
             g.st.dup_hits++;
         }
         if (h.exp_epoch != g.epoch) expand_node<G>(P, g, np, h, P.add_noise && leaf == g.root);
-        const uint32_t* path = P.paths + ((size_t)slot * SPRL_MAXQ + q) * P.max_depth;
-        uint32_t e0 = l < depth ? path[l] : 0u;
-        uint32_t e1 = 64 + l < depth ? path[64 + l] : 0u;
         backup_path<G>(g, e0, e1, depth, h.player, h.value);
     }
     g.n_leaves = 0;

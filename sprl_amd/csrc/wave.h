@@ -115,8 +115,11 @@ SPRL_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, 
 SPRL_DEV unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 SPRL_DEV uint32_t atomic_cas_u32(uint32_t* p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
 SPRL_DEV void atomic_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// make this wave's completed global stores visible to its own other lanes (same CU, same L1)
-SPRL_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+// Order this wave's earlier global stores before its later loads from OTHER lanes of the same wave.  A wavefront's
+// vector memory instructions are issued and performed in order through one L1, so wavefront scope needs no
+// instruction on gfx9 (LLVM AMDGPU memory model: no code is emitted for wavefront-scope fences); this only stops
+// the compiler from reordering across it.
+SPRL_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 // Ownership of a memory region moving between wavefronts that may sit on different XCDs: the per-XCD L2s are
 // write-back and not coherent with each other, so the old owner writes its dirty lines back (buffer_wbl2) before
 // publishing the hand-off and the new owner invalidates its L1 after winning it (MI355X_MICROARCH.md,
