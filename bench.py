@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--node-cap", type=int, default=0, help="nodes per game arena (0 = engine default)")
     args = ap.parse_args()
 
     import torch
@@ -143,7 +144,7 @@ def main():
     total_steps = args.steps + args.warmup
     # unique RNG streams for every game of every step of every rank
     cfg = E.default_config("othello", lib, device=local_rank, concurrent_games=args.concurrent,
-                           num_traversals=args.traversals, seed=args.seed,
+                           num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
                            stream_base=1 + rank * games * (total_steps + 1), profile=0 if args.no_profile else 1)
     eng = E.Engine(cfg, lib)
     eng.set_model(model_path if model_path else args.model)
@@ -226,6 +227,11 @@ def main():
                       "nn_fill": d["nn_evals"] / max(1, d["nn_rows"]), "hbm_gib": st1["hbm_bytes"] / 2**30,
                       "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"]},
         }
+        if d.get("cyc_total", 0) > 0:
+            out["phase_cycles_share"] = {k[4:]: d[k] / d["cyc_total"] for k in d if k.startswith("cyc_") and k not in ("cyc_total", "cyc_max_slot_launch")}
+            out["phase_cycles_share"]["max_cycles_one_slot_launch"] = st1["cyc_max_slot_launch"]
+            out["phase_cycles_share"]["noise_cycles_per_move"] = d["cyc_noise"] / max(1, d["plies"])
+            out["phase_cycles_share"]["total_cycles_per_slot_launch"] = d["cyc_total"] / max(1, d["kernel_launches"]) / args.concurrent
         if not args.no_profile and d["kernel_ms"] > 0:
             achieved = d["traversals"] * bpt / (d["kernel_ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "step_kernel<Othello> (select/expand/backup/re-root)",

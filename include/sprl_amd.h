@@ -114,6 +114,9 @@ typedef struct sprl_stats {
     double kernel_ms;          /* sum of tree-kernel durations (HIP events; profile=1) */
     double nn_ms;              /* sum of network forward durations (HIP events; profile=1) */
     int64_t hbm_bytes;         /* device memory allocated by the engine */
+    /* shader-clock cycles summed over game slots, per phase; 0 unless built with -DSPRL_PHASE_TIMERS (diagnosis) */
+    int64_t cyc_total, cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise,
+        cyc_max_slot_launch;
 } sprl_stats;
 int sprl_engine_stats(sprl_engine* e, sprl_stats* out);
 

@@ -522,6 +522,15 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
         out->dup_hits += (int64_t)c.stats.dup_hits;
         out->nodes_created += (int64_t)c.stats.nodes_created;
         out->compactions += (int64_t)c.stats.compactions;
+        out->cyc_total += (int64_t)c.stats.cyc_total;
+        out->cyc_finish += (int64_t)c.stats.cyc_finish;
+        out->cyc_move += (int64_t)c.stats.cyc_move;
+        out->cyc_select += (int64_t)c.stats.cyc_select;
+        out->cyc_create += (int64_t)c.stats.cyc_create;
+        out->cyc_backup += (int64_t)c.stats.cyc_backup;
+        out->cyc_leafio += (int64_t)c.stats.cyc_leafio;
+        out->cyc_noise += (int64_t)c.stats.cyc_noise;
+        if ((int64_t)c.stats.cyc_max > out->cyc_max_slot_launch) out->cyc_max_slot_launch = (int64_t)c.stats.cyc_max;
         if ((int64_t)c.stats.max_alloc > out->max_nodes_in_arena) out->max_nodes_in_arena = (int64_t)c.stats.max_alloc;
     }
     out->rounds = e->rounds;

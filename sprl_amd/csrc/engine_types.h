@@ -54,6 +54,9 @@ struct NodeHdr {            // 64 bytes at node + 896
 struct GameStats {
     unsigned long long traversals, levels, expansions, nn_evals, terminal_hits, gray_hits, dup_hits,
         nodes_created, compactions, games, plies, max_alloc;
+    // shader-clock cycles per phase, filled only by the diagnostic build (-DSPRL_PHASE_TIMERS), else 0
+    unsigned long long cyc_total, cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio,
+        cyc_noise, cyc_max;
 };
 
 struct GameCtl {

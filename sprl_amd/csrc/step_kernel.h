@@ -63,7 +63,13 @@ struct Game {                 // per-wave working state (wave-uniform values)
     uint32_t arena, root, n_alloc, epoch, root_player, game_id, status;
     float rootN, rootW;
     int ply, traversals, n_leaves;
-    GameStats st;
+    // per-launch counter deltas (32-bit: keeps the wave's scalar registers free for the search itself); they are
+    // added to the 64-bit totals in GameCtl once, when the slot's state is written back
+    uint32_t d_traversals, d_levels, d_expansions, d_nn_evals, d_terminal, d_gray, d_dup, d_created, d_compactions,
+        d_games, d_plies;
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+    unsigned long long cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise;
+#endif
 };
 
 SPRL_DEV void raise_error(const EngineParams& P, Game& g, uint32_t code) {
@@ -111,40 +117,49 @@ SPRL_DEV Pos pos_of(const NodeHdr& h) {
 // expand (UCTNode::expand, uct/UCTNode.hpp:312-348).  The P row already holds the cached, legal-masked
 // network policy; N and W rows are (re)initialised here, which is what EdgeStatistics::reset() left behind.
 // ---------------------------------------------------------------------------------------------------
+// Dirichlet root noise (UCTNode.hpp:330-347): rare (once per move) and heavy (serial gamma draws in double
+// arithmetic), so it is kept out of line to keep the descent loop's code and register footprint small.
+template <class G>
+SPRL_DEV_NOINLINE void mix_root_noise(const EngineParams& P, Game& g, uint8_t* np, uint64_t legal, bool pass_legal,
+                                      float pass_p) {
+    const int l = wv::lane();
+    NodeHdr* h = hdr_of(np);
+    SPRL_TIC(t_nz);
+    const int num_legal = wv::popc64(legal) + (pass_legal ? 1 : 0);
+    const bool mine = (legal >> l) & 1ull;
+    const int my_rank = wv::popc64(legal & wv::lt_mask(l));
+    NormalState ns = { 0.0f, 0 };
+    float my_noise = 0.0f, pass_noise = 0.0f, sum = 0.0f;
+    for (int i = 0; i < num_legal; ++i) {                 // Random::Dirichlet, utils/random.cpp:61-74
+        float s = rng_gamma(g.rng, ns, P.dir_alpha);
+        sum += s;
+        if (mine && my_rank == i) my_noise = s;
+        if (i == num_legal - 1 && pass_legal) pass_noise = s;
+    }
+    const float norm = 1.0f / sum;
+    my_noise *= norm;
+    pass_noise *= norm;
+    const double keep = 1.0 - (double)P.dir_eps;          // UCTNode.hpp:341-343 (double arithmetic)
+    if (mine) {
+        float p = rowP(np)[l];
+        rowP(np)[l] = (float)(keep * (double)p + (double)(P.dir_eps * my_noise));
+    }
+    if (pass_legal) h->passP = (float)(keep * (double)pass_p + (double)(P.dir_eps * pass_noise));
+    SPRL_TOC(g.cyc_noise, t_nz);
+}
+
 template <class G>
 SPRL_DEV void expand_node(const EngineParams& P, Game& g, uint8_t* np, const NodeHdr& hc, bool add_noise) {
     const int l = wv::lane();
     NodeHdr* h = hdr_of(np);
-    const uint64_t legal = hc.legal;
     const bool pass_legal = G::HAS_PASS && (hc.flags & F_PASS);
     rowN(np)[l] = 0.0f;
     rowW(np)[l] = 0.0f;
     h->passN = 0.0f;
     h->passW = 0.0f;
     h->exp_epoch = g.epoch;
-    if (add_noise) {
-        const int num_legal = wv::popc64(legal) + (pass_legal ? 1 : 0);
-        const bool mine = (legal >> l) & 1ull;
-        const int my_rank = wv::popc64(legal & wv::lt_mask(l));
-        NormalState ns = { 0.0f, 0 };
-        float my_noise = 0.0f, pass_noise = 0.0f, sum = 0.0f;
-        for (int i = 0; i < num_legal; ++i) {                 // Random::Dirichlet, utils/random.cpp:61-74
-            float s = rng_gamma(g.rng, ns, P.dir_alpha);
-            sum += s;
-            if (mine && my_rank == i) my_noise = s;
-            if (i == num_legal - 1 && pass_legal) pass_noise = s;
-        }
-        const float norm = 1.0f / sum;
-        my_noise *= norm;
-        pass_noise *= norm;
-        const double keep = 1.0 - (double)P.dir_eps;          // UCTNode.hpp:341-343 (double arithmetic)
-        if (mine) {
-            float p = rowP(np)[l];
-            rowP(np)[l] = (float)(keep * (double)p + (double)(P.dir_eps * my_noise));
-        }
-        if (pass_legal) h->passP = (float)(keep * (double)hc.passP + (double)(P.dir_eps * pass_noise));
-    }
-    g.st.expansions++;
+    if (add_noise) mix_root_noise<G>(P, g, np, hc.legal, pass_legal, hc.passP);
+    g.d_expansions++;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -155,6 +170,7 @@ SPRL_DEV void backup_path(Game& g, uint32_t my_entry0, uint32_t my_entry1, int d
     // Lane j owns path edge j (and j + 64): all W loads go out together, then all stores — two memory round
     // trips per backup instead of one per level.  The edges of one path are distinct addresses.
     const int l = wv::lane();
+    SPRL_TIC(t_bk);
     wv::sync();         // (emulator) the descent's own stores to these edges precede the read-modify-write below
     const float est = -value * (leaf_player == 0 ? 1.0f : -1.0f);
     g.rootW += 1.0f + est * (g.root_player == 0 ? 1.0f : -1.0f);
@@ -174,6 +190,7 @@ SPRL_DEV void backup_path(Game& g, uint32_t my_entry0, uint32_t my_entry1, int d
         }
     }
     wv::wave_fence();   // edges were updated by lane j, they are read back by lane `action` / as header fields
+    SPRL_TOC(g.cyc_backup, t_bk);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -281,7 +298,7 @@ SPRL_DEV void finish_leaves(const EngineParams& P, Game& g, int slot, GameCtl* c
         if (!(h.flags & F_EVAL)) {
             evaluate_leaf<G>(P, g, np, h, sym, my_logit, pass_logit, nn_value);
         } else {
-            g.st.dup_hits++;
+            g.d_dup++;
         }
         if (h.exp_epoch != g.epoch) expand_node<G>(P, g, np, h, P.add_noise && leaf == g.root);
         backup_path<G>(g, e0, e1, depth, h.player, h.value);
@@ -328,7 +345,7 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
                 const int r = rng_uniform_int(g.rng, (uint32_t)k);
                 a = wv::nth_set_bit(ties, r);
             }
-            g.st.levels++;
+            g.d_levels++;
             if (depth >= P.max_depth) { raise_error(P, g, ERR_MAX_DEPTH); return; }
             if (l == 0) lds_path[depth] = (cur << 8) | (uint32_t)a;
             ++depth;
@@ -348,12 +365,14 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
             bool created = false;
             Pos cs;
             if (c == SPRL_NONE16) {
+                SPRL_TIC(t_cr);
                 c = g.n_alloc++;
                 created = true;
                 G::child(pos_of(h), a, cs);
                 write_new_node<G>(node_at(g.abase, c), cs, a);
+                SPRL_TOC(g.cyc_create, t_cr);
                 w_a = h.value;                              // InitQ::PARENT (UCTNode.hpp:271-273)
-                g.st.nodes_created++;
+                g.d_created++;
                 if (G::HAS_PASS && a == SPRL_PASS) hp->passChild = c;
                 else if (l == a) rowC(np)[l] = (uint16_t)c;
             }
@@ -381,14 +400,14 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
             uint32_t e0 = l < depth ? lds_path[l] : 0u;
             uint32_t e1 = 64 + l < depth ? lds_path[64 + l] : 0u;
             backup_path<G>(g, e0, e1, depth, h.player, value);
-            g.st.terminal_hits++;
+            g.d_terminal++;
             continue;
         } else if (h.flags & F_EVAL) {
             expand_node<G>(P, g, node_at(g.abase, cur), h, P.add_noise && cur == g.root);
             uint32_t e0 = l < depth ? lds_path[l] : 0u;
             uint32_t e1 = 64 + l < depth ? lds_path[64 + l] : 0u;
             backup_path<G>(g, e0, e1, depth, h.player, h.value);
-            g.st.gray_hits++;
+            g.d_gray++;
             continue;
         } else {
             const int q = g.n_leaves++;
@@ -401,8 +420,9 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         if (g.n_leaves >= P.max_queue) break;
     }
     g.traversals += trav;
-    g.st.traversals += (unsigned long long)trav;
+    g.d_traversals += (uint32_t)trav;
     // symmetry draws in queue order (UCTTree.hpp:141-149), then the input planes for the network
+    SPRL_TIC(t_io);
     for (int q = 0; q < g.n_leaves; ++q) {
         int sym = 0;
         if (P.use_sym) sym = rng_uniform_int(g.rng, (uint32_t)G::NSYM);
@@ -412,7 +432,8 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
             encode_leaf<G>(P, lh, sym, slot * P.max_queue + q);
         }
     }
-    g.st.nn_evals += (unsigned long long)g.n_leaves;
+    g.d_nn_evals += (uint32_t)g.n_leaves;
+    SPRL_TOC(g.cyc_leafio, t_io);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -424,7 +445,7 @@ SPRL_DEV void copy_node(const uint8_t* src, uint8_t* dst) {
 }
 
 template <class G>
-SPRL_DEV bool compact_arena(const EngineParams& P, Game& g) {
+SPRL_DEV_NOINLINE bool compact_arena(const EngineParams& P, Game& g) {
     const int l = wv::lane();
     // acquire a spare arena
     uint32_t got = 0xFFFFFFFFu;
@@ -474,7 +495,7 @@ SPRL_DEV bool compact_arena(const EngineParams& P, Game& g) {
     g.abase = to;
     g.root = 0;
     g.n_alloc = free_;
-    g.st.compactions++;
+    g.d_compactions++;
     return true;
 }
 
@@ -482,7 +503,7 @@ SPRL_DEV bool compact_arena(const EngineParams& P, Game& g) {
 // new game / move
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV void start_game(const EngineParams& P, Game& g) {
+SPRL_DEV_NOINLINE void start_game(const EngineParams& P, Game& g) {
     uint32_t gid = 0;
     if (wv::lane() == 0) gid = wv::atomic_add_u32(&P.counters->next_game, 1u);
     gid = wv::bcast_u32(gid, 0);
@@ -505,12 +526,12 @@ SPRL_DEV void start_game(const EngineParams& P, Game& g) {
     g.ply = 0;
     g.traversals = 0;
     g.n_leaves = 0;
-    g.st.nodes_created++;
+    g.d_created++;
 }
 
 // SelfPlay.hpp:110-148: visit pdf, temperature, CDF sample, record, re-root
 template <class G>
-SPRL_DEV void play_move(const EngineParams& P, Game& g) {
+SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g) {
     const int l = wv::lane();
     uint8_t* np = node_at(g.abase, g.root);
     const NodeHdr hcopy = load_hdr(np);
@@ -587,7 +608,7 @@ SPRL_DEV void play_move(const EngineParams& P, Game& g) {
     g.ply += 1;
     g.epoch += 1;
     g.traversals = 0;
-    g.st.plies++;
+    g.d_plies++;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -612,24 +633,29 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
     g.traversals = ctl->traversals;
     g.n_leaves = ctl->n_leaves;
     g.root_player = ctl->root_player;
-    g.st = ctl->stats;
+    g.d_traversals = g.d_levels = g.d_expansions = g.d_nn_evals = g.d_terminal = g.d_gray = g.d_dup = 0;
+    g.d_created = g.d_compactions = g.d_games = g.d_plies = 0;
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+    g.cyc_finish = g.cyc_move = g.cyc_select = g.cyc_create = g.cyc_backup = g.cyc_leafio = g.cyc_noise = 0;
+#endif
     g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * SPRL_NODE_BYTES;
     wv::sync();
 
+    SPRL_TIC(t_all);
     if (g.status == ST_FRESH) start_game<G>(P, g);
 
     for (int round = 0; round < P.rounds && g.status == ST_ACTIVE; ++round) {
-        if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl);
+        { SPRL_TIC(t_f); if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl); SPRL_TOC(g.cyc_finish, t_f); }
         // while (traversals < numTraversals) ... ; then the move; then the next ply's search begins
         bool idle = false;
         while (g.traversals >= P.num_traversals) {
-            play_move<G>(P, g);
+            { SPRL_TIC(t_m); play_move<G>(P, g); SPRL_TOC(g.cyc_move, t_m); }
             if (g.status != ST_ACTIVE) break;
             const NodeHdr rh = load_hdr(node_at(g.abase, g.root));
             if (rh.flags & F_TERMINAL) {                          // SelfPlay.hpp:85,151
                 P.rec_nplies[g.game_id] = g.ply;
                 P.rec_winner[g.game_id] = rh.winner;
-                g.st.games++;
+                g.d_games++;
                 if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
                 start_game<G>(P, g);
                 if (g.status != ST_ACTIVE) { idle = true; break; }
@@ -640,8 +666,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
             if (!compact_arena<G>(P, g)) break;
             if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
         }
-        select_batch<G>(P, g, slot, ctl, lds_path);
-        if (g.n_alloc > g.st.max_alloc) g.st.max_alloc = g.n_alloc;
+        { SPRL_TIC(t_s); select_batch<G>(P, g, slot, ctl, lds_path); SPRL_TOC(g.cyc_select, t_s); }
     }
 
     ctl->status = g.status;
@@ -658,7 +683,29 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
     ctl->traversals = g.traversals;
     ctl->n_leaves = g.n_leaves;
     ctl->root_player = g.root_player;
-    ctl->stats = g.st;
+    if (wv::lane() == 0) {                       // one lane: these are read-modify-writes of wave-uniform locations
+        GameStats& t = ctl->stats;
+        t.traversals += g.d_traversals;
+        t.levels += g.d_levels;
+        t.expansions += g.d_expansions;
+        t.nn_evals += g.d_nn_evals;
+        t.terminal_hits += g.d_terminal;
+        t.gray_hits += g.d_gray;
+        t.dup_hits += g.d_dup;
+        t.nodes_created += g.d_created;
+        t.compactions += g.d_compactions;
+        t.games += g.d_games;
+        t.plies += g.d_plies;
+        if (g.n_alloc > t.max_alloc) t.max_alloc = g.n_alloc;
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_all;
+        t.cyc_total += dt;
+        if (dt > t.cyc_max) t.cyc_max = dt;
+        t.cyc_finish += g.cyc_finish; t.cyc_move += g.cyc_move; t.cyc_select += g.cyc_select;
+        t.cyc_create += g.cyc_create; t.cyc_backup += g.cyc_backup; t.cyc_leafio += g.cyc_leafio;
+        t.cyc_noise += g.cyc_noise;
+#endif
+    }
     P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
     if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
 }

@@ -85,7 +85,9 @@ static inline void agent_acquire() {}
 // ------------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
 #define SPRL_DEV __device__ __forceinline__
-#define SPRL_DEV_NOINLINE __device__ __noinline__
+// Out-of-line device calls were measured and rejected: passing the wave state by reference puts it in scratch
+// (360 B/lane) and the launch got 1.8x slower, so the rare heavy paths stay inlined too.
+#define SPRL_DEV_NOINLINE __device__ __forceinline__
 
 namespace wv {
 SPRL_DEV int lane() { return (int)(threadIdx.x & 63u); }
@@ -135,6 +137,14 @@ SPRL_DEV void agent_acquire() {
 // lanes of a wavefront execute in lockstep: nothing to do on hardware (see the emulator's sync())
 SPRL_DEV void sync() { __builtin_amdgcn_wave_barrier(); }
 }  // namespace wv
+#endif
+
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+#define SPRL_TIC(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define SPRL_TOC(acc, var) (acc) += __builtin_amdgcn_s_memtime() - (var)
+#else
+#define SPRL_TIC(var) do { } while (0)
+#define SPRL_TOC(acc, var) do { } while (0)
 #endif
 
 namespace wv {
