@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "liboracle.so")
 
-GAME_OTHELLO, GAME_C4 = 0, 1
+GAME_OTHELLO, GAME_C4, GAME_GO7 = 0, 1, 2
 EVAL_RANDOM, EVAL_HEURISTIC, EVAL_CALLBACK = 0, 1, 2
 MATH_LIBM, MATH_PORTABLE = 0, 1
 MASK_REFERENCE, MASK_SYMMETRISED = 0, 1
@@ -69,14 +69,14 @@ def lib():
                                C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_symmetrize_board.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_symmetrize_dist.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.orc_evaluate.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 5
-        L.orc_encode_planes.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_evaluate.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 6
+        L.orc_encode_planes.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_decode_policy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_search_trace.argtypes = [C.POINTER(Config), C.c_int, C.c_uint64, C.c_int] + [C.c_void_p] * 3
         L.orc_selfplay.argtypes = [C.POINTER(Config), C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int] + \
-            [C.c_void_p] * 5 + [C.POINTER(Stats)]
+            [C.c_void_p] * 6 + [C.POINTER(Stats)]
         L.orc_write_npy_f32.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
-        L.orc_write_records.argtypes = [C.POINTER(Config), C.c_char_p, C.c_int] + [C.c_void_p] * 4
+        L.orc_write_records.argtypes = [C.POINTER(Config), C.c_char_p, C.c_int] + [C.c_void_p] * 5
         _lib = L
     return _lib
 
@@ -85,12 +85,15 @@ def vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-GEOM = {GAME_OTHELLO: dict(rows=8, cols=8, cells=64, A=65, nsym=8), GAME_C4: dict(rows=6, cols=7, cells=42, A=7, nsym=2)}
+GEOM = {GAME_OTHELLO: dict(rows=8, cols=8, cells=64, A=65, nsym=8, hist=1),
+        GAME_C4: dict(rows=6, cols=7, cells=42, A=7, nsym=2, hist=1),
+        GAME_GO7: dict(rows=7, cols=7, cells=49, A=50, nsym=8, hist=8)}
 
 # the reference workers' constants: OTHWorker.cpp:24-28, C4Worker.cpp:23-27, constants.hpp:6-10
 DEFAULTS = {
     GAME_OTHELLO: dict(max_batch=8, max_queue=4, dir_eps=0.25, dir_alpha=0.3),
     GAME_C4: dict(max_batch=8, max_queue=4, dir_eps=0.25, dir_alpha=0.5),
+    GAME_GO7: dict(max_batch=16, max_queue=8, dir_eps=0.25, dir_alpha=0.2),     # GoWorker.cpp:23-27
 }
 
 
@@ -124,7 +127,7 @@ def make_forward(fn, game):
     g = GEOM[game]
 
     def _cb(user, n, planes, logits, values):
-        x = np.ctypeslib.as_array(planes, shape=(n, 3, g["rows"], g["cols"]))
+        x = np.ctypeslib.as_array(planes, shape=(n, 2 * g["hist"] + 1, g["rows"], g["cols"]))
         lo, va = fn(x.copy())
         np.ctypeslib.as_array(logits, shape=(n, g["A"]))[:] = np.asarray(lo, np.float32).reshape(n, g["A"])
         np.ctypeslib.as_array(values, shape=(n,))[:] = np.asarray(va, np.float32).reshape(n)
@@ -136,17 +139,18 @@ def selfplay(cfg, num_games, seed, stream_base=1, per_game_stream=True, cap=None
     g = GEOM[cfg.game]
     if cap is None:
         cap = num_games * 130 * (g["nsym"] if cfg.use_sym else 1)
-    boards = np.zeros((cap, g["cells"]), np.int8)
+    boards = np.zeros((cap, g["hist"] * g["cells"]), np.int8)
     players = np.zeros(cap, np.int8)
+    sizes = np.zeros(cap, np.int8)
     dists = np.zeros((cap, g["A"]), np.float32)
     outcomes = np.zeros(cap, np.float32)
     offs = np.zeros(num_games + 1, np.int32)
     st = Stats()
     n = lib().orc_selfplay(C.byref(cfg), num_games, seed, stream_base, int(per_game_stream), cap,
-                           vp(boards), vp(players), vp(dists), vp(outcomes), vp(offs), C.byref(st))
+                           vp(boards), vp(players), vp(sizes), vp(dists), vp(outcomes), vp(offs), C.byref(st))
     if n < 0:
         raise RuntimeError("oracle selfplay: capacity exceeded")
-    return dict(boards=boards[:n], players=players[:n], dists=dists[:n], outcomes=outcomes[:n],
+    return dict(boards=boards[:n], players=players[:n], sizes=sizes[:n], dists=dists[:n], outcomes=outcomes[:n],
                 offsets=offs, stats=st.as_dict())
 
 
@@ -161,7 +165,7 @@ def search_trace(cfg, moves, seed, stream=1):
 
 def playout(game, seed, stream=1, max_plies=200):
     g = GEOM[game]
-    boards = np.zeros((max_plies, g["cells"]), np.int8)
+    boards = np.zeros((max_plies, g["hist"] * g["cells"]), np.int8)
     players = np.zeros(max_plies, np.int8)
     actions = np.zeros(max_plies, np.int16)
     masks = np.zeros((max_plies, g["A"]), np.float32)
@@ -206,7 +210,7 @@ def evaluate(cfg, boards, players, masks):
     n = len(players)
     pol = np.zeros((n, g["A"]), np.float32)
     val = np.zeros(n, np.float32)
-    lib().orc_evaluate(C.byref(cfg), n, vp(boards), vp(players), vp(masks), vp(pol), vp(val))
+    lib().orc_evaluate(C.byref(cfg), n, vp(boards), vp(players), None, vp(masks), vp(pol), vp(val))
     return pol, val
 
 
@@ -218,4 +222,4 @@ def rng_stream(seed, stream, n):
 
 def write_records(cfg, prefix, res):
     return lib().orc_write_records(C.byref(cfg), prefix.encode(), len(res["players"]), vp(res["boards"]),
-                                   vp(res["players"]), vp(res["dists"]), vp(res["outcomes"]))
+                                   vp(res["players"]), vp(res["sizes"]), vp(res["dists"]), vp(res["outcomes"]))

@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_ref", "libsprl_ref.so")
 LIB_TORCH = os.path.join(HERE, "_ref", "libsprl_ref_torch.so")
 
-GEOM = {"othello": dict(cells=64, A=65, nsym=8), "c4": dict(cells=42, A=7, nsym=2)}
+GEOM = {"othello": dict(cells=64, A=65, nsym=8, hist=1), "c4": dict(cells=42, A=7, nsym=2, hist=1),
+        "go": dict(cells=49, A=50, nsym=8, hist=8)}
 
 
 def available(torch=False):
@@ -43,6 +44,12 @@ def lib(torch=False):
                 [C.c_uint64] + [C.c_int] * 3 + [C.c_void_p] * 5
             getattr(L, f"ref_{g}_search_trace").argtypes = [C.c_int] * 5 + [C.c_float] * 2 + [C.c_int] * 2 + \
                 [C.c_uint64, C.c_int] + [C.c_void_p] * 3
+        L.ref_go_playout.argtypes = [C.c_uint64, C.c_int, C.c_int] + [C.c_void_p] * 6
+        L.ref_go_selfplay.argtypes = [C.c_int] * 5 + [C.c_float] * 2 + [C.c_int] * 2 + [C.c_uint64] + [C.c_int] * 3 + \
+            [C.c_void_p] * 6
+        L.ref_go_search_trace.argtypes = [C.c_int] * 5 + [C.c_float] * 2 + [C.c_int] * 2 + [C.c_uint64, C.c_int] + \
+            [C.c_void_p] * 3
+        L.ref_go_komi.restype = C.c_float
         L.ref_othello_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         L.ref_othello_evaluate.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5
         L.ref_c4_known_answer.argtypes = [C.c_void_p]
@@ -68,16 +75,18 @@ def selfplay(game, eval_kind, num_games, traversals, max_batch, max_queue, eps, 
              per_game_stream=True, use_sym=1, add_noise=1, model_path=None):
     g = GEOM[game]
     cap = num_games * 130 * (g["nsym"] if use_sym else 1)
-    boards = np.zeros((cap, g["cells"]), np.int8)
+    boards = np.zeros((cap, g["hist"] * g["cells"]), np.int8)
     players = np.zeros(cap, np.int8)
+    sizes = np.ones(cap, np.int8)
     dists = np.zeros((cap, g["A"]), np.float32)
     outcomes = np.zeros(cap, np.float32)
     offs = np.zeros(num_games + 1, np.int32)
     evals = None
     if model_path is None:
+        extra = (vp(sizes),) if game == "go" else ()
         n = getattr(lib(), f"ref_{game}_selfplay")(eval_kind, num_games, traversals, max_batch, max_queue, eps, alpha,
                                                    use_sym, add_noise, seed, stream_base, int(per_game_stream), cap,
-                                                   vp(boards), vp(players), vp(dists), vp(outcomes), vp(offs))
+                                                   vp(boards), vp(players), vp(dists), vp(outcomes), vp(offs), *extra)
     else:
         ne = np.zeros(1, np.int64)
         n = getattr(lib(True), f"ref_torch_{game}_selfplay")(model_path.encode(), num_games, traversals, max_batch,
@@ -87,8 +96,8 @@ def selfplay(game, eval_kind, num_games, traversals, max_batch, max_queue, eps, 
         evals = int(ne[0])
     if n < 0:
         raise RuntimeError("reference selfplay: capacity exceeded")
-    return dict(boards=boards[:n], players=players[:n], dists=dists[:n], outcomes=outcomes[:n], offsets=offs,
-                evals=evals)
+    return dict(boards=boards[:n], players=players[:n], sizes=sizes[:n], dists=dists[:n], outcomes=outcomes[:n],
+                offsets=offs, evals=evals)
 
 
 def search_trace(game, eval_kind, moves, traversals, max_batch, max_queue, eps, alpha, seed, stream=1,
@@ -104,7 +113,7 @@ def search_trace(game, eval_kind, moves, traversals, max_batch, max_queue, eps, 
 
 def playout(game, seed, stream=1, max_plies=200):
     g = GEOM[game]
-    boards = np.zeros((max_plies, g["cells"]), np.int8)
+    boards = np.zeros((max_plies, g["hist"] * g["cells"]), np.int8)
     players = np.zeros(max_plies, np.int8)
     actions = np.zeros(max_plies, np.int16)
     masks = np.zeros((max_plies, g["A"]), np.float32)

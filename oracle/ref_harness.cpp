@@ -18,6 +18,7 @@
 
 #include "games/OthelloNode.hpp"
 #include "games/ConnectFourNode.hpp"
+#include "games/GoNode.hpp"
 #include "networks/RandomNetwork.hpp"
 #include "networks/OthelloHeuristic.hpp"
 #include "symmetry/D4GridSymmetrizer.hpp"
@@ -57,6 +58,15 @@ struct OthTraits {
     using Sym = D4GridSymmetrizer<OTH_BOARD_WIDTH, OTH_HISTORY_SIZE>;
 };
 
+struct GoTraits {                      // the reference compiles Go as 7x7 (games/GoNode.hpp:16-22)
+    using Node = GoNode;
+    static constexpr int CELLS = GO_BOARD_SIZE;
+    static constexpr int HIST = GO_HISTORY_SIZE;
+    static constexpr int A = GO_ACTION_SIZE;
+    using State = GridState<CELLS, HIST>;
+    using Sym = D4GridSymmetrizer<GO_BOARD_WIDTH, GO_HISTORY_SIZE>;
+};
+
 struct C4Traits {
     using Node = ConnectFourNode;
     static constexpr int CELLS = C4_BOARD_SIZE;
@@ -87,11 +97,15 @@ INetwork<typename T::State, T::A>* makeEvaluator(int kind) {
     return new RandomNetwork<typename T::State, T::A>();
 }
 
+// boards: [HIST][CELLS]; plies t >= size() are not defined by the reference and are written as -2
 template <typename T>
-void dumpState(const typename T::State& s, int8_t* board, int8_t* player) {
+void dumpState(const typename T::State& s, int8_t* board, int8_t* player, int8_t* size = nullptr) {
     const auto& h = s.getHistory();
-    for (int i = 0; i < T::CELLS; ++i) board[i] = static_cast<int8_t>(h[0][i]);
+    for (int t = 0; t < T::HIST; ++t)
+        for (int i = 0; i < T::CELLS; ++i)
+            board[t * T::CELLS + i] = t < s.size() ? static_cast<int8_t>(h[t][i]) : (int8_t)-2;
     *player = static_cast<int8_t>(s.getPlayer());
+    if (size) *size = (int8_t)s.size();
 }
 
 // Random legal play-out through the GameNode API (G1).
@@ -104,7 +118,7 @@ int playout(uint64_t seed, int stream, int maxPlies,
     GameNode<typename T::Node, typename T::State, T::A>* node = &root;
     int ply = 0;
     while (true) {
-        dumpState<T>(node->getGameState(), boards + ply * T::CELLS, players + ply);
+        dumpState<T>(node->getGameState(), boards + ply * T::HIST * T::CELLS, players + ply);
         const auto& m = node->getActionMask();
         for (int a = 0; a < T::A; ++a) masks[ply * T::A + a] = m[a];
         terminal[ply] = node->isTerminal();
@@ -128,7 +142,8 @@ template <typename T>
 int selfplayGames(int evalKind, void* netOverride, int numGames, int numTraversals, int maxBatch, int maxQueue,
                   float eps, float alpha, int useSym, int addNoise,
                   uint64_t seed, int streamBase, int perGameStream, int cap,
-                  int8_t* boards, int8_t* players, float* dists, float* outcomes, int32_t* gameOffsets) {
+                  int8_t* boards, int8_t* players, float* dists, float* outcomes, int32_t* gameOffsets,
+                  int8_t* sizes = nullptr) {
     typename T::Sym sym;
     INetwork<typename T::State, T::A>* net =
         netOverride ? static_cast<INetwork<typename T::State, T::A>*>(netOverride) : makeEvaluator<T>(evalKind);
@@ -143,7 +158,7 @@ int selfplayGames(int evalKind, void* netOverride, int numGames, int numTraversa
         gameOffsets[g] = n;
         for (size_t i = 0; i < states.size(); ++i) {
             if (n >= cap) return -1;
-            dumpState<T>(states[i], boards + (size_t)n * T::CELLS, players + n);
+            dumpState<T>(states[i], boards + (size_t)n * T::HIST * T::CELLS, players + n, sizes ? sizes + n : nullptr);
             for (int a = 0; a < T::A; ++a) dists[(size_t)n * T::A + a] = distributions[i][a];
             outcomes[n] = outs[i];
             ++n;
@@ -329,6 +344,28 @@ int ref_c4_selfplay(int evalKind, int numGames, int numTraversals, int maxBatch,
                                    addNoise, seed, streamBase, perGameStream, cap, boards, players, dists, outcomes,
                                    gameOffsets);
 }
+
+int ref_go_playout(uint64_t seed, int stream, int maxPlies, int8_t* boards, int8_t* players,
+                   int16_t* actions, float* masks, int8_t* terminal, float* rewards) {
+    return playout<GoTraits>(seed, stream, maxPlies, boards, players, actions, masks, terminal, rewards);
+}
+int ref_go_selfplay(int evalKind, int numGames, int numTraversals, int maxBatch, int maxQueue,
+                    float eps, float alpha, int useSym, int addNoise,
+                    uint64_t seed, int streamBase, int perGameStream, int cap,
+                    int8_t* boards, int8_t* players, float* dists, float* outcomes, int32_t* gameOffsets,
+                    int8_t* sizes) {
+    return selfplayGames<GoTraits>(evalKind, nullptr, numGames, numTraversals, maxBatch, maxQueue, eps, alpha, useSym,
+                                   addNoise, seed, streamBase, perGameStream, cap, boards, players, dists, outcomes,
+                                   gameOffsets, sizes);
+}
+int ref_go_search_trace(int evalKind, int moves, int numTraversals, int maxBatch, int maxQueue,
+                        float eps, float alpha, int useSym, int addNoise, uint64_t seed, int stream,
+                        float* stats, int32_t* trav, int16_t* chosen) {
+    return searchTrace<GoTraits>(evalKind, moves, numTraversals, maxBatch, maxQueue, eps, alpha, useSym, addNoise,
+                                 seed, stream, stats, trav, chosen);
+}
+int ref_go_board_width() { return GO_BOARD_WIDTH; }
+float ref_go_komi() { return GO_KOMI; }
 
 int ref_othello_search_trace(int evalKind, int moves, int numTraversals, int maxBatch, int maxQueue,
                              float eps, float alpha, int useSym, int addNoise, uint64_t seed, int stream,

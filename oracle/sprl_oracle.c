@@ -24,6 +24,8 @@ static geom_t geom(int game) {
     geom_t g;
     if (game == ORC_GAME_C4) {           /* games/ConnectFourNode.hpp:8-13 */
         g.rows = 6; g.cols = 7; g.cells = 42; g.A = 7; g.nsym = 2; g.hist = 1;
+    } else if (game == ORC_GAME_GO7) {   /* games/GoNode.hpp:16-22: 7x7, 8-ply history, 49 + pass */
+        g.rows = 7; g.cols = 7; g.cells = 49; g.A = 50; g.nsym = 8; g.hist = 8;
     } else {                             /* games/OthelloNode.hpp:8-11 */
         g.rows = 8; g.cols = 8; g.cells = 64; g.A = 65; g.nsym = 8; g.hist = 1;
     }
@@ -35,6 +37,7 @@ int orc_game_actions(int game) { return geom(game).A; }
 int orc_game_nsym(int game) { return geom(game).nsym; }
 int orc_game_rows(int game) { return geom(game).rows; }
 int orc_game_cols(int game) { return geom(game).cols; }
+int orc_game_hist(int game) { return geom(game).hist; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* math dispatch                                                                               */
@@ -286,12 +289,216 @@ static void c4_step(const int8_t* board, int player, const float* mask, int acti
         for (int c = 0; c < 7; ++c) nmask[c] = 0.0f;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* Go 7x7 — games/GoNode.{hpp,cpp}, utils/DSU.hpp, utils/Zobrist.hpp                            */
+/* ------------------------------------------------------------------------------------------ */
+#define GO_W 7
+#define GO_N 49
+#define GO_PASS 49
+#define GO_MAX_DEPTH (2 * GO_N)                  /* GoNode.hpp:22 */
+#define GO_KOMI 9.0f                             /* GoNode.hpp:20 */
+
+typedef struct {
+    int8_t board[GO_N];
+    int8_t dsu[GO_N];                            /* utils/DSU.hpp (path compression omitted: same sets) */
+    int8_t libs[GO_N];                           /* valid at group roots */
+    uint64_t comp[GO_N];                         /* per-group Zobrist value, valid at group roots */
+    uint64_t hash;
+    int depth;
+    int action;                                  /* action that led here (m_action), 0 at the start node */
+    uint64_t hist[GO_MAX_DEPTH + 2];             /* m_zobristHistorySet: hashes after every placement */
+    int nhist;
+} go_state;
+
+/* The reference draws its Zobrist table from the process-global RNG at static-init time (Zobrist.hpp:42-47),
+ * i.e. it is random per process and only matters through collisions; any fixed table is equivalent. */
+static uint64_t go_zobrist(int coord, int piece) {
+    uint64_t z = 0x9E3779B97F4A7C15ULL * (uint64_t)(coord + piece * GO_N + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static int go_neighbors(int c, int* out) {                                   /* GoNode.hpp:117-130 */
+    int n = 0, row = c / GO_W, col = c % GO_W;
+    if (row > 0) out[n++] = c - GO_W;
+    if (col > 0) out[n++] = c - 1;
+    if (row < GO_W - 1) out[n++] = c + GO_W;
+    if (col < GO_W - 1) out[n++] = c + 1;
+    return n;
+}
+static int go_find(const go_state* s, int x) {
+    while (s->dsu[x] != x) x = s->dsu[x];
+    return x;
+}
+static int go_has_hash(const go_state* s, uint64_t h) {
+    for (int i = 0; i < s->nhist; ++i)
+        if (s->hist[i] == h) return 1;
+    return 0;
+}
+static int go_compute_liberties(const go_state* s, int coord) {              /* GoNode.cpp:10-52 */
+    int piece = s->board[coord];
+    if (piece == -1) return 0;
+    int visited[GO_N] = { 0 }, q[GO_N], qh = 0, qt = 0, libs = 0, nb[4];
+    visited[coord] = 1;
+    q[qt++] = coord;
+    while (qh < qt) {
+        int cur = q[qh++];
+        int k = go_neighbors(cur, nb);
+        for (int i = 0; i < k; ++i) {
+            int n = nb[i];
+            if (s->board[n] == piece) {
+                if (!visited[n]) { visited[n] = 1; q[qt++] = n; }
+            } else if (s->board[n] == -1) {
+                if (!visited[n]) { visited[n] = 1; ++libs; }
+            }
+        }
+    }
+    return libs;
+}
+static void go_clear_component(go_state* s, int coord, int piece) {          /* GoNode.cpp:54-94 */
+    s->board[coord] = -1;
+    s->dsu[coord] = (int8_t)coord;
+    s->libs[go_find(s, coord)] = 0;
+    s->comp[go_find(s, coord)] = 0;
+    int groups[4], ng = 0, nb[4];
+    int k = go_neighbors(coord, nb);
+    for (int i = 0; i < k; ++i) {
+        int n = nb[i];
+        if (s->board[n] == -1) continue;
+        if (s->board[n] == piece) {
+            go_clear_component(s, n, piece);
+        } else {
+            int grp = go_find(s, n), seen = 0;
+            for (int j = 0; j < ng; ++j)
+                if (groups[j] == grp) seen = 1;
+            if (seen) continue;
+            groups[ng++] = grp;
+            s->libs[grp]++;
+        }
+    }
+}
+static void go_place(go_state* s, int coord, int piece) {                    /* GoNode.cpp:96-176 */
+    int nb[4];
+    s->board[coord] = (int8_t)piece;
+    uint64_t new_comp = go_zobrist(coord, piece);
+    int k = go_neighbors(coord, nb);
+    for (int i = 0; i < k; ++i) {
+        int n = nb[i];
+        if (s->board[n] == piece) {
+            if (go_find(s, n) == go_find(s, coord)) continue;
+            new_comp ^= s->comp[go_find(s, n)];
+            int rx = go_find(s, n), ry = go_find(s, coord);                  /* DSU::unite(neighbor, coord) */
+            if (rx != ry) s->dsu[rx] = (int8_t)ry;
+        }
+    }
+    s->comp[go_find(s, coord)] = new_comp;
+    s->libs[go_find(s, coord)] = (int8_t)go_compute_liberties(s, coord);
+    uint64_t update = go_zobrist(coord, piece);
+    int groups[4], ng = 0;
+    for (int i = 0; i < k; ++i) {
+        int n = nb[i];
+        if (s->board[n] == 1 - piece) {
+            int grp = go_find(s, n), seen = 0;
+            for (int j = 0; j < ng; ++j)
+                if (groups[j] == grp) seen = 1;
+            if (seen) continue;
+            groups[ng++] = grp;
+            s->libs[grp]--;
+            if (s->libs[go_find(s, grp)] == 0) {
+                update ^= s->comp[go_find(s, grp)];
+                go_clear_component(s, grp, 1 - piece);
+            }
+        }
+    }
+    s->hash ^= update;
+    s->hist[s->nhist++] = s->hash;
+}
+static int go_legal(const go_state* s, int coord, int piece) {               /* GoNode.cpp:178-228 */
+    if (s->board[coord] != -1) return 0;
+    uint64_t nh = s->hash ^ go_zobrist(coord, piece);
+    int has_libs = 0, groups[4], ng = 0, nb[4];
+    int k = go_neighbors(coord, nb);
+    for (int i = 0; i < k; ++i) {
+        int n = nb[i];
+        if (s->board[n] == -1) {
+            has_libs = 1;
+        } else if (s->board[n] == piece) {
+            if (s->libs[go_find(s, n)] > 1) has_libs = 1;
+        } else {
+            if (s->libs[go_find(s, n)] == 1) {
+                has_libs = 1;
+                int grp = go_find(s, n), seen = 0;
+                for (int j = 0; j < ng; ++j)
+                    if (groups[j] == grp) seen = 1;
+                if (seen) continue;
+                groups[ng++] = grp;
+                nh ^= s->comp[grp];
+            }
+        }
+    }
+    return has_libs && !go_has_hash(s, nh);
+}
+static void go_territory(const go_state* s, int* terr) {                     /* GoNode.cpp:230-290 */
+    int visited[GO_N] = { 0 }, nb[4];
+    terr[0] = terr[1] = 0;
+    for (int i = 0; i < GO_N; ++i) {
+        if (s->board[i] == 0) { terr[0]++; continue; }
+        if (s->board[i] == 1) { terr[1]++; continue; }
+        if (visited[i]) continue;
+        int q[GO_N], qh = 0, qt = 0, count = 0, poss0 = 1, poss1 = 1;
+        visited[i] = 1;
+        q[qt++] = i;
+        while (qh < qt) {
+            int cur = q[qh++];
+            ++count;
+            int k = go_neighbors(cur, nb);
+            for (int j = 0; j < k; ++j) {
+                int n = nb[j];
+                if (s->board[n] == 0) poss1 = 0;
+                else if (s->board[n] == 1) poss0 = 0;
+                else if (!visited[n]) { visited[n] = 1; q[qt++] = n; }
+            }
+        }
+        if (poss0 && !poss1) terr[0] += count;
+        if (poss1 && !poss0) terr[1] += count;
+    }
+}
+static void go_start(go_state* s) {                                          /* GoNode.cpp:303-317 */
+    memset(s, 0, sizeof(*s));
+    memset(s->board, -1, GO_N);
+    for (int i = 0; i < GO_N; ++i) s->dsu[i] = (int8_t)i;
+}
+static void go_next(const go_state* p, int player, int action, go_state* c, float* mask, int* terminal,
+                    int* winner) {                                           /* GoNode.cpp:319-383 */
+    *c = *p;
+    if (action != GO_PASS) go_place(c, action, player);
+    c->action = action;
+    c->depth = p->depth + 1;
+    *terminal = (p->action == GO_PASS && action == GO_PASS) || c->depth >= GO_MAX_DEPTH;
+    *winner = -1;
+    for (int a = 0; a < 50; ++a) mask[a] = 0.0f;
+    if (!*terminal) {
+        for (int i = 0; i < GO_N; ++i) mask[i] = (float)go_legal(c, i, 1 - player);
+        mask[GO_PASS] = 1.0f;                                                /* :298 */
+    } else {
+        int terr[2];
+        go_territory(c, terr);
+        float s0 = (float)terr[0], s1 = (float)terr[1];
+        s1 += GO_KOMI;
+        if ((double)s0 > (double)s1 + 0.1) *winner = 0;
+        else if ((double)s1 > (double)s0 + 0.1) *winner = 1;
+    }
+}
+
 void orc_start(int game, int8_t* board, int* player, float* mask) {
     geom_t g = geom(game);
     memset(board, -1, (size_t)g.cells);
     *player = 0;
     if (game == ORC_GAME_C4) {                                               /* ConnectFourNode.cpp:13-21 */
         for (int a = 0; a < 7; ++a) mask[a] = 1.0f;
+    } else if (game == ORC_GAME_GO7) {                                       /* GoNode.cpp:306 */
+        for (int a = 0; a < 50; ++a) mask[a] = 1.0f;
     } else {                                                                 /* OthelloNode.cpp:18-32 */
         board[3 * 8 + 3] = 1;
         board[3 * 8 + 4] = 0;
@@ -314,21 +521,32 @@ static void rewards_of(int winner, float* rw) {                              /* 
 
 int orc_playout(int game, uint64_t seed, int stream, int max_plies, int8_t* boards, int8_t* players,
                 int16_t* actions, float* masks, int8_t* terminal, float* rewards) {
+    /* boards: [max_plies][hist][cells]; for Go the 8-ply history is filled newest first, missing plies = -2 */
     geom_t g = geom(game);
     orc_rng rng;
     orc_rng_seed(&rng, seed, stream);
     int8_t b[ORC_MAX_CELLS], nb[ORC_MAX_CELLS];
     float m[ORC_MAX_A], nm[ORC_MAX_A];
     int player, term = 0, winner = -1, ply = 0;
+    go_state* gs = NULL;
     orc_start(game, b, &player, m);
+    if (game == ORC_GAME_GO7) {
+        gs = (go_state*)malloc(sizeof(go_state) * (size_t)(max_plies + 1));
+        go_start(&gs[0]);
+    }
+    const size_t stride = (size_t)g.hist * g.cells;
     for (;;) {
-        memcpy(boards + (size_t)ply * g.cells, b, (size_t)g.cells);
+        memset(boards + (size_t)ply * stride, -2, stride);
+        for (int t = 0; t < g.hist && t <= ply; ++t)
+            memcpy(boards + (size_t)ply * stride + (size_t)t * g.cells,
+                   gs ? gs[ply - t].board : b, (size_t)g.cells);
         players[ply] = (int8_t)player;
         memcpy(masks + (size_t)ply * g.A, m, (size_t)g.A * sizeof(float));
         terminal[ply] = (int8_t)term;
         rewards_of(winner, rewards + 2 * ply);
         if (term || ply + 1 >= max_plies) {
             actions[ply] = -1;
+            free(gs);
             return ply + 1;
         }
         int legal[ORC_MAX_A], nl = 0;
@@ -336,7 +554,12 @@ int orc_playout(int game, uint64_t seed, int stream, int max_plies, int8_t* boar
             if (m[a] > 0.0f) legal[nl++] = a;
         int a = legal[orc_uniform_int(&rng, 0, nl - 1)];
         actions[ply] = (int16_t)a;
-        orc_step(game, b, player, m, a, nb, nm, &term, &winner);
+        if (gs) {
+            go_next(&gs[ply], player, a, &gs[ply + 1], nm, &term, &winner);
+            memcpy(nb, gs[ply + 1].board, GO_N);
+        } else {
+            orc_step(game, b, player, m, a, nb, nm, &term, &winner);
+        }
         memcpy(b, nb, (size_t)g.cells);
         memcpy(m, nm, (size_t)g.A * sizeof(float));
         player = 1 - player;
@@ -401,18 +624,22 @@ int orc_inverse_symmetry(int game, int sym) {
 /* evaluators                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 
-void orc_encode_planes(int game, int n, const int8_t* boards, const int8_t* players, float* planes) {
+void orc_encode_planes(int game, int n, const int8_t* boards, const int8_t* players, const int8_t* sizes,
+                       float* planes) {
     geom_t g = geom(game);                                                   /* GridNetwork.hpp:72-97 */
     int P = 2 * g.hist + 1;
     for (int b = 0; b < n; ++b) {
         float* out = planes + (size_t)b * P * g.cells;
         int ours = players[b];
-        for (int i = 0; i < g.cells; ++i) {
-            int8_t v = boards[(size_t)b * g.cells + i];
-            out[i] = v == ours ? 1.0f : 0.0f;
-            out[g.cells + i] = v == 1 - ours ? 1.0f : 0.0f;
-            out[2 * g.cells + i] = ours == 0 ? 1.0f : 0.0f;
-        }
+        int size = sizes ? sizes[b] : g.hist;
+        memset(out, 0, (size_t)P * g.cells * sizeof(float));
+        for (int t = 0; t < size; ++t)
+            for (int i = 0; i < g.cells; ++i) {
+                int8_t v = boards[((size_t)b * g.hist + t) * g.cells + i];
+                if (v == ours) out[(2 * t) * g.cells + i] = 1.0f;
+                else if (v == 1 - ours) out[(2 * t + 1) * g.cells + i] = 1.0f;
+            }
+        for (int i = 0; i < g.cells; ++i) out[(2 * g.hist) * g.cells + i] = ours == 0 ? 1.0f : 0.0f;
     }
 }
 
@@ -434,14 +661,14 @@ void orc_decode_policy(int A, const float* logits, const float* mask, float* pol
     }
 }
 
-void orc_evaluate(const orc_config* cfg, int n, const int8_t* boards, const int8_t* players,
+void orc_evaluate(const orc_config* cfg, int n, const int8_t* boards, const int8_t* players, const int8_t* sizes,
                   const float* masks, float* policies, float* values) {
     geom_t g = geom(cfg->game);
     if (cfg->eval_kind == ORC_EVAL_CALLBACK) {
         int P = 2 * g.hist + 1;
         float* planes = (float*)malloc((size_t)n * P * g.cells * sizeof(float));
         float* logits = (float*)malloc((size_t)n * g.A * sizeof(float));
-        orc_encode_planes(cfg->game, n, boards, players, planes);
+        orc_encode_planes(cfg->game, n, boards, players, sizes, planes);
         cfg->forward(cfg->forward_user, n, planes, logits, values);
         for (int b = 0; b < n; ++b)
             orc_decode_policy(g.A, logits + (size_t)b * g.A, masks + (size_t)b * g.A,
@@ -460,7 +687,7 @@ void orc_evaluate(const orc_config* cfg, int n, const int8_t* boards, const int8
         for (int i = 0; i < g.A; ++i) pol[i] = mask[i] > 0.0f ? uniform : 0.0f;
         values[b] = 0.0f;
         if (cfg->eval_kind == ORC_EVAL_HEURISTIC && cfg->game == ORC_GAME_OTHELLO) {
-            const int8_t* bd = boards + (size_t)b * g.cells;                 /* OthelloHeuristic.cpp:28-49 */
+            const int8_t* bd = boards + (size_t)b * g.hist * g.cells;        /* OthelloHeuristic.cpp:28-49 */
             int num_empty = 0;
             for (int i = 0; i < 64; ++i)
                 if (bd[i] == -1) ++num_empty;
@@ -491,6 +718,7 @@ typedef struct node {
     float P[ORC_MAX_A], W[ORC_MAX_A], N[ORC_MAX_A];  /* EdgeStatistics, UCTNode.hpp:45-60 */
     float* own_N;                                    /* UCTNode.hpp:142 */
     float* own_W;                                    /* UCTNode.hpp:147 */
+    go_state* go;                                    /* Go only: DSU / liberties / hashes (GoNode members) */
 } node;
 
 typedef struct {
@@ -509,13 +737,23 @@ static node* node_new(tree* t, node* parent, int action) {
     n->parent = parent;
     n->action = action;
     if (parent) {
-        orc_step(t->cfg->game, parent->board, parent->player, parent->mask, action, n->board, n->mask,
-                 &n->terminal, &n->winner);
+        if (t->cfg->game == ORC_GAME_GO7) {
+            n->go = (go_state*)malloc(sizeof(go_state));
+            go_next(parent->go, parent->player, action, n->go, n->mask, &n->terminal, &n->winner);
+            memcpy(n->board, n->go->board, GO_N);
+        } else {
+            orc_step(t->cfg->game, parent->board, parent->player, parent->mask, action, n->board, n->mask,
+                     &n->terminal, &n->winner);
+        }
         n->player = 1 - parent->player;
         n->own_N = &parent->N[action];
         n->own_W = &parent->W[action];
     } else {
         orc_start(t->cfg->game, n->board, &n->player, n->mask);
+        if (t->cfg->game == ORC_GAME_GO7) {
+            n->go = (go_state*)malloc(sizeof(go_state));
+            go_start(n->go);
+        }
         n->winner = -1;
         n->own_N = &t->dummy_N[0];
         n->own_W = &t->dummy_W[0];
@@ -532,6 +770,7 @@ static int64_t node_free(node* n, int A) {
     if (!n) return 0;
     int64_t c = 1;
     for (int a = 0; a < A; ++a) c += node_free(n->children[a], A);
+    free(n->go);
     free(n);
     return c;
 }
@@ -634,16 +873,34 @@ static int search_and_get_leaves(tree* t, node** leaves, int* nleaves) {     /* 
     return traversals;
 }
 
+/* getGameState: the node's board, and for Go up to 8 boards walking the parents, newest first
+ * (GoNode.cpp:385-398); returns the number of valid plies. */
+static int node_state(const tree* t, const node* n, int8_t* boards) {
+    int size = 0;
+    memset(boards, -2, (size_t)t->g.hist * t->g.cells);
+    for (const node* cur = n; cur && size < t->g.hist; cur = cur->parent, ++size)
+        memcpy(boards + (size_t)size * t->g.cells, cur->board, (size_t)t->g.cells);
+    return size;
+}
+
+static void symmetrize_state(const tree* t, int sym, int size, const int8_t* in, int8_t* out) {
+    memset(out, -2, (size_t)t->g.hist * t->g.cells);
+    for (int p = 0; p < size; ++p)                                           /* D4GridSymmetrizer.hpp:63-71 */
+        orc_symmetrize_board(t->cfg->game, sym, in + (size_t)p * t->g.cells, out + (size_t)p * t->g.cells);
+}
+
 static void evaluate_and_backprop(tree* t, node** leaves, int n) {           /* UCTTree.hpp:124-184 */
     geom_t g = t->g;
-    int8_t* boards = (int8_t*)malloc((size_t)n * g.cells);
+    const size_t stride = (size_t)g.hist * g.cells;
+    int8_t* boards = (int8_t*)malloc((size_t)n * stride);
+    int8_t* sizes = (int8_t*)malloc((size_t)n);
     int8_t* players = (int8_t*)malloc((size_t)n);
     float* masks = (float*)malloc((size_t)n * g.A * sizeof(float));
     float* policies = (float*)malloc((size_t)n * g.A * sizeof(float));
     float* values = (float*)malloc((size_t)n * sizeof(float));
     int syms[64];
     for (int i = 0; i < n; ++i) {
-        memcpy(boards + (size_t)i * g.cells, leaves[i]->board, (size_t)g.cells);
+        sizes[i] = (int8_t)node_state(t, leaves[i], boards + (size_t)i * stride);
         players[i] = (int8_t)leaves[i]->player;
         memcpy(masks + (size_t)i * g.A, leaves[i]->mask, (size_t)g.A * sizeof(float));
         syms[i] = 0;
@@ -651,14 +908,14 @@ static void evaluate_and_backprop(tree* t, node** leaves, int n) {           /* 
     if (t->cfg->use_sym) {
         for (int i = 0; i < n; ++i) {
             syms[i] = orc_uniform_int(t->rng, 0, g.nsym - 1);
-            int8_t tmp[ORC_MAX_CELLS];
-            orc_symmetrize_board(t->cfg->game, syms[i], leaves[i]->board, tmp);
-            memcpy(boards + (size_t)i * g.cells, tmp, (size_t)g.cells);
+            int8_t tmp[ORC_MAX_HIST * ORC_MAX_CELLS];
+            memcpy(tmp, boards + (size_t)i * stride, stride);
+            symmetrize_state(t, syms[i], sizes[i], tmp, boards + (size_t)i * stride);
             if (t->cfg->mask_frame == ORC_MASK_SYMMETRISED)
                 orc_symmetrize_dist(t->cfg->game, syms[i], leaves[i]->mask, masks + (size_t)i * g.A);
         }
     }
-    orc_evaluate(t->cfg, n, boards, players, masks, policies, values);
+    orc_evaluate(t->cfg, n, boards, players, sizes, masks, policies, values);
     if (t->st) t->st->nn_evals += n;
     for (int i = 0; i < n; ++i) {
         node* leaf = leaves[i];
@@ -680,7 +937,7 @@ static void evaluate_and_backprop(tree* t, node** leaves, int n) {           /* 
         if (!leaf->expanded) expand(t, leaf, t->cfg->add_noise && leaf == t->decision);
         backup(t, leaf, leaf->net_value);
     }
-    free(boards); free(players); free(masks); free(policies); free(values);
+    free(boards); free(sizes); free(players); free(masks); free(policies); free(values);
 }
 
 static void clear_subtree(tree* t, node* n) {                                /* UCTTree.hpp:283-298 */
@@ -754,7 +1011,7 @@ int orc_search_trace(const orc_config* cfg, int moves, uint64_t seed, int stream
 
 /* One game of self-play — selfplay/SelfPlay.hpp:51-192.  Returns number of samples appended, -1 on overflow. */
 static int self_play(const orc_config* cfg, orc_rng* rng, orc_stats* st, int cap, int n0,
-                     int8_t* boards, int8_t* players, float* dists, float* outcomes) {
+                     int8_t* boards, int8_t* players, int8_t* sizes, float* dists, float* outcomes) {
     tree t;
     tree_init(&t, cfg, rng, st);
     geom_t g = t.g;
@@ -762,11 +1019,18 @@ static int self_play(const orc_config* cfg, orc_rng* rng, orc_stats* st, int cap
     int nsym = cfg->use_sym ? g.nsym : 1;
     int n = n0, move_count = 0;
     int movers[1024];
+    (void)sizes;
     while (!t.decision->terminal) {
         if (n + nsym > cap) { node_free(t.root, A); return -1; }
-        for (int s = 0; s < nsym; ++s) {                                     /* :86-96 */
-            orc_symmetrize_board(cfg->game, s, t.decision->board, boards + (size_t)(n + s) * g.cells);
-            players[n + s] = (int8_t)t.decision->player;
+        {
+            int8_t cur[ORC_MAX_HIST * ORC_MAX_CELLS];
+            const size_t stride = (size_t)g.hist * g.cells;
+            int size = node_state(&t, t.decision, cur);
+            for (int s = 0; s < nsym; ++s) {                                 /* :86-96 */
+                symmetrize_state(&t, s, size, cur, boards + (size_t)(n + s) * stride);
+                players[n + s] = (int8_t)t.decision->player;
+                if (sizes) sizes[n + s] = (int8_t)size;
+            }
         }
         search_move(&t);
 
@@ -810,7 +1074,7 @@ static int self_play(const orc_config* cfg, orc_rng* rng, orc_stats* st, int cap
 }
 
 int orc_selfplay(const orc_config* cfg, int num_games, uint64_t seed, int stream_base, int per_game_stream,
-                 int cap, int8_t* boards, int8_t* players, float* dists, float* outcomes,
+                 int cap, int8_t* boards, int8_t* players, int8_t* sizes, float* dists, float* outcomes,
                  int32_t* game_offsets, orc_stats* stats) {                  /* SelfPlay.hpp:204-248 */
     orc_rng rng;
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -819,7 +1083,7 @@ int orc_selfplay(const orc_config* cfg, int num_games, uint64_t seed, int stream
     for (int gi = 0; gi < num_games; ++gi) {
         if (per_game_stream) orc_rng_seed(&rng, seed, stream_base + gi);
         game_offsets[gi] = n;
-        int k = self_play(cfg, &rng, stats, cap, n, boards, players, dists, outcomes);
+        int k = self_play(cfg, &rng, stats, cap, n, boards, players, sizes, dists, outcomes);
         if (k < 0) return -1;
         n += k;
     }
@@ -865,11 +1129,11 @@ int orc_write_npy_f32(const char* path, const float* data, int ndim, const uint6
 }
 
 int orc_write_records(const orc_config* cfg, const char* path_prefix, int n, const int8_t* boards,
-                      const int8_t* players, const float* dists, const float* outcomes) {
+                      const int8_t* players, const int8_t* sizes, const float* dists, const float* outcomes) {
     geom_t g = geom(cfg->game);
     int P = 2 * g.hist + 1;
     float* planes = (float*)malloc((size_t)n * P * g.cells * sizeof(float));
-    orc_encode_planes(cfg->game, n, boards, players, planes);                /* same layout: GridWorker.hpp:146-171 */
+    orc_encode_planes(cfg->game, n, boards, players, sizes, planes);         /* same layout: GridWorker.hpp:146-171 */
     char path[4096];
     uint64_t s4[4] = { (uint64_t)n, (uint64_t)P, (uint64_t)g.rows, (uint64_t)g.cols };
     uint64_t s2[2] = { (uint64_t)n, (uint64_t)g.A };

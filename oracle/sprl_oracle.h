@@ -29,7 +29,8 @@ extern "C" {
 #define ORC_MAX_A 128
 #define ORC_MAX_CELLS 128
 
-enum { ORC_GAME_OTHELLO = 0, ORC_GAME_C4 = 1 };
+enum { ORC_GAME_OTHELLO = 0, ORC_GAME_C4 = 1, ORC_GAME_GO7 = 2 };
+#define ORC_MAX_HIST 8
 enum { ORC_EVAL_RANDOM = 0, ORC_EVAL_HEURISTIC = 1, ORC_EVAL_CALLBACK = 2 };
 enum { ORC_MATH_LIBM = 0, ORC_MATH_PORTABLE = 1 };
 enum { ORC_MASK_REFERENCE = 0, ORC_MASK_SYMMETRISED = 1 };
@@ -70,6 +71,7 @@ int orc_game_actions(int game);
 int orc_game_nsym(int game);
 int orc_game_rows(int game);
 int orc_game_cols(int game);
+int orc_game_hist(int game);
 
 /* RNG: PCG32 + libstdc++ distribution algorithms (utils/random.{hpp,cpp}) */
 typedef struct { uint64_t state, inc; } orc_rng;
@@ -93,9 +95,11 @@ void orc_symmetrize_dist(int game, int sym, const float* in, float* out);
 int orc_inverse_symmetry(int game, int sym);
 
 /* evaluators on explicit batches (boards already symmetrised, masks in original frame) */
-void orc_evaluate(const orc_config* cfg, int n, const int8_t* boards, const int8_t* players,
+/* boards: [n][hist][cells] (plies t >= sizes[i] ignored; sizes may be NULL = all `hist` plies valid) */
+void orc_evaluate(const orc_config* cfg, int n, const int8_t* boards, const int8_t* players, const int8_t* sizes,
                   const float* masks, float* policies, float* values);
-void orc_encode_planes(int game, int n, const int8_t* boards, const int8_t* players, float* planes);
+void orc_encode_planes(int game, int n, const int8_t* boards, const int8_t* players, const int8_t* sizes,
+                       float* planes);
 void orc_decode_policy(int A, const float* logits, const float* mask, float* policy, int math_mode);
 
 /* search trace: same contract as ref_*_search_trace in ref_harness.cpp */
@@ -103,14 +107,15 @@ int orc_search_trace(const orc_config* cfg, int moves, uint64_t seed, int stream
                      float* stats, int32_t* trav, int16_t* chosen);
 
 /* self-play: same contract as ref_*_selfplay in ref_harness.cpp */
+/* boards: [cap][hist][cells] (history plies beyond sizes[i] are written as -2), sizes: [cap] or NULL */
 int orc_selfplay(const orc_config* cfg, int num_games, uint64_t seed, int stream_base, int per_game_stream,
-                 int cap, int8_t* boards, int8_t* players, float* dists, float* outcomes,
+                 int cap, int8_t* boards, int8_t* players, int8_t* sizes, float* dists, float* outcomes,
                  int32_t* game_offsets, orc_stats* stats);
 
 /* records: plane encoding (GridWorker.hpp:146-171) + .npy v1.0 writer (utils/npy.hpp:430-476) */
 int orc_write_npy_f32(const char* path, const float* data, int ndim, const uint64_t* shape);
 int orc_write_records(const orc_config* cfg, const char* path_prefix, int n, const int8_t* boards,
-                      const int8_t* players, const float* dists, const float* outcomes);
+                      const int8_t* players, const int8_t* sizes, const float* dists, const float* outcomes);
 
 #ifdef __cplusplus
 }

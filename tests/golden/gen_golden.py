@@ -61,7 +61,7 @@ def g6_rng():
 
 def g1_playouts():
     out = {}
-    for game in ("othello", "c4"):
+    for game in ("othello", "c4", "go"):
         for i, seed in enumerate((11, 22, 33, 44)):
             r = pyref.playout(game, seed, 1)
             for k, v in r.items():
@@ -101,6 +101,8 @@ def g4_search():
                 out[key + "_chosen"] = ch
     # Q8 demonstration: start-position priors per forced symmetry cannot be forced from outside; instead
     # keep a no-noise trace whose root priors show zeros where the drawn symmetry moved the mask (Q1).
+    st, tr, ch = pyref.search_trace("go", 0, 3, 200, 16, 8, 0.25, 0.2, SEED, 1)
+    out["go_k0_b16q8_stats"], out["go_k0_b16q8_trav"], out["go_k0_b16q8_chosen"] = st, tr, ch
     st, tr, ch = pyref.search_trace("othello", 0, 1, 16, 8, 4, 0.25, 0.3, SEED, 1, use_sym=1, add_noise=0)
     out["othello_nonoise_stats"] = st
     save("g4_search.npz", **out)
@@ -124,6 +126,10 @@ def g5_games():
     r = pyref.selfplay("othello", 0, 1, 30, 1, 1, 0.25, 0.3, SEED, 3, True, use_sym=0, add_noise=0)
     for k in ("boards", "players", "dists", "outcomes", "offsets"):
         out["oth_nosym_b1q1_" + k] = r[k]
+    # Go 7x7 (the size the reference compiles, GoNode.hpp:16): 8-ply history states, superko, Tromp-Taylor + komi
+    r = pyref.selfplay("go", 0, 3, 120, 16, 8, 0.25, 0.2, SEED, 1, True)
+    for k in ("boards", "players", "sizes", "dists", "outcomes", "offsets"):
+        out["go_random_" + k] = r[k]
     save("g5_games.npz", **out)
 
     # worker byte streams (runWorker + vendored npy writer)

@@ -11,7 +11,7 @@ from oracle import pyoracle as po
 from oracle import pyref
 
 SEED = 12345
-GAMES = {"othello": po.GAME_OTHELLO, "c4": po.GAME_C4}
+GAMES = {"othello": po.GAME_OTHELLO, "c4": po.GAME_C4, "go": po.GAME_GO7}
 
 
 def bits(a):
@@ -46,7 +46,7 @@ def test_g6_distributions(golden):
     assert r.state == int(g["final_state"][0])       # same number of engine draws consumed
 
 
-@pytest.mark.parametrize("game", ["othello", "c4"])
+@pytest.mark.parametrize("game", ["othello", "c4", "go"])
 def test_g1_playouts(golden, game):
     g = golden("g1_playouts.npz")
     for i in range(4):
@@ -90,7 +90,7 @@ def test_g2_symmetries(golden, game):
 @pytest.mark.parametrize("key,game,kind,mb,mq,alpha", [
     ("othello_k0_b8q4", "othello", 0, 8, 4, 0.3), ("othello_k0_b1q1", "othello", 0, 1, 1, 0.3),
     ("othello_k1_b8q4", "othello", 1, 8, 4, 0.3), ("othello_k1_b1q1", "othello", 1, 1, 1, 0.3),
-    ("c4_k0_b8q4", "c4", 0, 8, 4, 0.5), ("c4_k0_b1q1", "c4", 0, 1, 1, 0.5)])
+    ("c4_k0_b8q4", "c4", 0, 8, 4, 0.5), ("c4_k0_b1q1", "c4", 0, 1, 1, 0.5), ("go_k0_b16q8", "go", 0, 16, 8, 0.2)])
 def test_g4_search_trace(golden, key, game, kind, mb, mq, alpha):
     g = golden("g4_search.npz")
     cfg = po.make_config(GAMES[game], 200, max_batch=mb, max_queue=mq, dir_alpha=alpha, eval_kind=kind)
@@ -117,6 +117,7 @@ CASES = [
     ("c4_single_stream", po.GAME_C4, dict(num_traversals=100), 3, 9, False),
     ("oth_nosym_b1q1", po.GAME_OTHELLO, dict(num_traversals=30, max_batch=1, max_queue=1, use_sym=0, add_noise=0),
      1, 3, True),
+    ("go_random", po.GAME_GO7, dict(num_traversals=120), 3, 1, True),
 ]
 
 
@@ -128,6 +129,8 @@ def test_g5_whole_games(golden, name, game, kw, ngames, stream, per_game):
     assert (r["offsets"] == g[name + "_offsets"]).all()
     assert (r["boards"] == g[name + "_boards"]).all()
     assert (r["players"] == g[name + "_players"]).all()
+    if name + "_sizes" in g.files:
+        assert (r["sizes"] == g[name + "_sizes"]).all()          # 8-ply history: number of valid plies per sample
     assert (bits(r["dists"]) == bits(g[name + "_dists"])).all()
     assert (r["outcomes"] == g[name + "_outcomes"]).all()
     s = r["stats"]
@@ -202,7 +205,7 @@ def test_g9_network_contract(golden):
 @pytest.mark.skipif(not pyref.available(), reason="prebuilt reference library not present")
 @pytest.mark.parametrize("game,kind,trav,mb,mq,alpha,ngames", [
     ("othello", 0, 200, 8, 4, 0.3, 2), ("othello", 1, 100, 8, 4, 0.3, 2), ("othello", 0, 64, 1, 1, 0.3, 1),
-    ("c4", 0, 100, 8, 4, 0.5, 6), ("c4", 0, 512, 8, 4, 0.5, 2)])
+    ("c4", 0, 100, 8, 4, 0.5, 6), ("c4", 0, 512, 8, 4, 0.5, 2), ("go", 0, 400, 16, 8, 0.2, 3)])
 def test_live_reference_whole_games(game, kind, trav, mb, mq, alpha, ngames):
     """Fresh seeds (not in the fixtures): oracle == reference build, bit for bit."""
     seed = 424242 + trav
@@ -210,6 +213,6 @@ def test_live_reference_whole_games(game, kind, trav, mb, mq, alpha, ngames):
     cfg = po.make_config(GAMES[game], trav, max_batch=mb, max_queue=mq, dir_alpha=alpha, eval_kind=kind)
     o = po.selfplay(cfg, ngames, seed, 3, True)
     assert (o["offsets"] == r["offsets"]).all()
-    for k in ("boards", "players", "outcomes"):
+    for k in ("boards", "players", "sizes", "outcomes"):
         assert (o[k] == r[k]).all()
     assert (bits(o["dists"]) == bits(r["dists"])).all()
