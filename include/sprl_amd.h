@@ -27,7 +27,9 @@ extern "C" {
 #define SPRL_E_IO       (-6)  /* file could not be written */
 #define SPRL_E_LIMIT    (-7)  /* game longer than max_plies / line deeper than the path buffer */
 
-enum { SPRL_OTHELLO = 0, SPRL_CONNECT_FOUR = 1 };
+/* SPRL_GO7: Go as the reference compiles it — 7x7, komi 9.0, 8-ply history, positional superko, depth cap 98
+ * (games/GoNode.hpp:16-22) */
+enum { SPRL_OTHELLO = 0, SPRL_CONNECT_FOUR = 1, SPRL_GO7 = 2 };
 /* evaluator kinds: the reference's RandomNetwork (networks/RandomNetwork.hpp:15-57), OthelloHeuristic
  * (networks/OthelloHeuristic.cpp:5-53) and GridNetwork on a traced TorchScript file
  * (networks/GridNetwork.hpp:37-145) */
@@ -39,7 +41,7 @@ enum { SPRL_MASK_REFERENCE = 0, SPRL_MASK_SYMMETRISED = 1 };
 /* Replaces the compile-time constants of OTHWorker.cpp:12-28 / C4Worker.cpp:11-27 / constants.hpp:4-10
  * and the arguments of runIteration (selfplay/SelfPlay.hpp:204-209). */
 typedef struct sprl_config {
-    int32_t game;              /* SPRL_OTHELLO | SPRL_CONNECT_FOUR */
+    int32_t game;              /* SPRL_OTHELLO | SPRL_CONNECT_FOUR | SPRL_GO7 */
     int32_t device;            /* HIP device ordinal */
     int32_t concurrent_games;  /* game slots resident in HBM (one wavefront each) */
     int32_t num_traversals;    /* UCT traversals per move, lower bound (SelfPlay.hpp:100) */
@@ -63,7 +65,7 @@ typedef struct sprl_config {
 } sprl_config;
 
 /* Fills `cfg` with the reference worker's constants for `game` (OTHWorker.cpp:24-28, C4Worker.cpp:23-27,
- * constants.hpp:6-10), 800 traversals, 4096 concurrent games, seed 1. */
+ * GoWorker.cpp:23-27, constants.hpp:6-10), 800 traversals, 4096 concurrent games, seed 1. */
 int sprl_config_default(int32_t game, sprl_config* cfg);
 
 typedef struct sprl_engine sprl_engine;
@@ -87,6 +89,7 @@ int sprl_engine_set_forward(sprl_engine* e, sprl_forward_fn fn, void* user);
  * Sample order = the reference's: game-major, ply-major (SelfPlay.hpp:86-92,127-133,154-163).  */
 typedef struct sprl_records {
     int32_t game, num_games, rows, cols, cells, actions, nsym, use_symmetry;
+    int32_t history, planes;    /* H plies of history in a state (GridState.hpp:74-118), planes = 2H + 1 */
     int64_t total_plies;
     const int32_t* ply_offset;  /* [num_games + 1] */
     const int8_t* boards;       /* [total_plies][cells]  -1 empty, 0, 1 (GridState.hpp:18-22) */

@@ -21,9 +21,9 @@ bool ok(hipError_t e, const char* what) {
 // the top of its tree in that XCD's L2.
 template <class G>
 __global__ void __launch_bounds__(64) step_kernel(EngineParams P) {
-    __shared__ uint32_t lds_path[G::MAX_DEPTH];
+    __shared__ sprl::WaveLds<G> lds;
     const int slot = (int)blockIdx.x;
-    if (slot < P.num_slots) sprl::step_game<G>(P, slot, lds_path);
+    if (slot < P.num_slots) sprl::step_game<G>(P, slot, &lds);
 }
 
 // Exclusive scan of the per-slot leaf counts (slot order => the dense batch order is deterministic).
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) leaf_gather_kernel(EngineParams P, int flo
     const uint32_t cnt = P.leaf_count[slot];
     if (cnt == 0) return;
     const uint32_t off = P.leaf_offset[slot];
-    const int vec = floats_per_leaf / 4;
+    const int vec = (floats_per_leaf % 4 == 0) ? floats_per_leaf / 4 : 0;   // 16-byte copies only when rows stay aligned
     for (uint32_t q = 0; q < cnt; ++q) {
         const float4* src = (const float4*)(P.nn_in + ((size_t)slot * P.max_queue + q) * floats_per_leaf);
         float4* dst = (float4*)(P.nn_dense + (size_t)(off + q) * floats_per_leaf);
@@ -124,6 +124,7 @@ int sync() { return ok(hipStreamSynchronize(0), "hipStreamSynchronize") ? 0 : -1
 int launch_step(int game, const EngineParams& P) {
     dim3 grid((unsigned)P.num_slots), block(64);
     if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(step_kernel<Othello>, grid, block, 0, 0, P);
+    else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(step_kernel<Go7>, grid, block, 0, 0, P);
     else hipLaunchKernelGGL(step_kernel<ConnectFour>, grid, block, 0, 0, P);
     return ok(hipGetLastError(), "step_kernel launch") ? 0 : -1;
 }

@@ -30,21 +30,28 @@ int fail(int code, const std::string& msg) {
 }
 
 struct Geom {
-    int rows, cols, cells, A, nsym, max_depth, default_max_plies;
+    int rows, cols, cells, A, nsym, max_depth, default_max_plies, hist, planes, hist_cap;
 };
 
 Geom geom_of(int game) {
     if (game == SPRL_CONNECT_FOUR)
         return { ConnectFour::ROWS, ConnectFour::COLS, ConnectFour::CELLS, ConnectFour::A, ConnectFour::NSYM,
-                 ConnectFour::MAX_DEPTH, 48 };
-    return { Othello::ROWS, Othello::COLS, Othello::CELLS, Othello::A, Othello::NSYM, Othello::MAX_DEPTH, 128 };
+                 ConnectFour::MAX_DEPTH, 48, 1, 3, 1 };
+    if (game == SPRL_GO7)
+        return { Go7::ROWS, Go7::COLS, Go7::CELLS, Go7::A, Go7::NSYM, Go7::MAX_DEPTH, Go7::GAME_MAX_DEPTH + 2, Go7::HIST,
+                 Go7::PLANES, Go7::HIST_CAP };
+    return { Othello::ROWS, Othello::COLS, Othello::CELLS, Othello::A, Othello::NSYM, Othello::MAX_DEPTH, 128, 1, 3, 1 };
 }
 
 int map_cell(int game, int sym, int cell) {
-    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_cell(sym, cell) : Othello::map_cell(sym, cell);
+    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_cell(sym, cell)
+           : game == SPRL_GO7        ? Go7::map_cell(sym, cell)
+                                     : Othello::map_cell(sym, cell);
 }
 int map_action(int game, int sym, int a) {
-    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_action(sym, a) : Othello::map_action(sym, a);
+    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_action(sym, a)
+           : game == SPRL_GO7        ? Go7::map_action(sym, a)
+                                     : Othello::map_action(sym, a);
 }
 
 // LibTorch-ROCm evaluator plugin (libsprl_amd_torch.so), resolved lazily so the core has no torch dependency
@@ -154,16 +161,16 @@ int sprl_device_available(void) {
 }
 
 int sprl_config_default(int32_t game, sprl_config* cfg) {
-    if (!cfg || (game != SPRL_OTHELLO && game != SPRL_CONNECT_FOUR)) return fail(SPRL_E_CONFIG, "unknown game");
+    if (!cfg || (game != SPRL_OTHELLO && game != SPRL_CONNECT_FOUR && game != SPRL_GO7)) return fail(SPRL_E_CONFIG, "unknown game");
     memset(cfg, 0, sizeof(*cfg));
     cfg->game = game;
     cfg->device = 0;
     cfg->concurrent_games = 4096;
     cfg->num_traversals = 800;
-    cfg->max_batch = 8;                                   // OTHWorker.cpp:24, C4Worker.cpp:23
-    cfg->max_queue = 4;                                   // OTHWorker.cpp:25, C4Worker.cpp:24
-    cfg->dir_eps = 0.25f;                                 // OTHWorker.cpp:27, C4Worker.cpp:26
-    cfg->dir_alpha = game == SPRL_OTHELLO ? 0.3f : 0.5f;  // OTHWorker.cpp:28, C4Worker.cpp:27
+    cfg->max_batch = game == SPRL_GO7 ? 16 : 8;           // OTHWorker.cpp:24, C4Worker.cpp:23, GoWorker.cpp:23
+    cfg->max_queue = game == SPRL_GO7 ? 8 : 4;            // OTHWorker.cpp:25, C4Worker.cpp:24, GoWorker.cpp:24
+    cfg->dir_eps = 0.25f;                                 // OTHWorker.cpp:27, C4Worker.cpp:26, GoWorker.cpp:26
+    cfg->dir_alpha = game == SPRL_OTHELLO ? 0.3f : (game == SPRL_GO7 ? 0.2f : 0.5f);   // :28 / :27 / GoWorker.cpp:27
     cfg->u_weight = 1.1f;                                 // constants.hpp:6
     cfg->early_cutoff = 15;                               // constants.hpp:8
     cfg->early_exp = 0.98f;                               // constants.hpp:9
@@ -179,7 +186,8 @@ int sprl_config_default(int32_t game, sprl_config* cfg) {
 int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     if (!cfg || !out) return fail(SPRL_E_CONFIG, "null argument");
     *out = nullptr;
-    if (cfg->game != SPRL_OTHELLO && cfg->game != SPRL_CONNECT_FOUR) return fail(SPRL_E_CONFIG, "unknown game");
+    if (cfg->game != SPRL_OTHELLO && cfg->game != SPRL_CONNECT_FOUR && cfg->game != SPRL_GO7)
+        return fail(SPRL_E_CONFIG, "unknown game");
     if (cfg->concurrent_games < 1) return fail(SPRL_E_CONFIG, "concurrent_games must be >= 1");
     if (cfg->num_traversals < 1) return fail(SPRL_E_CONFIG, "num_traversals must be >= 1");
     if (cfg->max_batch < 1) return fail(SPRL_E_CONFIG, "max_batch must be >= 1");
@@ -218,7 +226,7 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.node_cap = (int)cap;
     P.max_plies = cfg->max_plies > 0 ? cfg->max_plies : e->g.default_max_plies;
     P.max_depth = e->g.max_depth;
-    P.planes = 3;
+    P.planes = e->g.planes;
     P.rounds = 1;
 
     const size_t arenas = (size_t)(P.num_slots + P.num_spare);
@@ -229,13 +237,14 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     ok = ok && (P.arena_used = (uint32_t*)dev_alloc(e, arenas * sizeof(uint32_t)));
     ok = ok && (P.ctl = (GameCtl*)dev_alloc(e, (size_t)P.num_slots * sizeof(GameCtl)));
     ok = ok && (P.paths = (uint32_t*)dev_alloc(e, npaths * (size_t)P.max_depth * sizeof(uint32_t)));
-    ok = ok && (P.nn_in = (float*)dev_alloc(e, nq * 3 * (size_t)e->g.cells * sizeof(float)));
-    ok = ok && (P.nn_dense = (float*)dev_alloc(e, nq * 3 * (size_t)e->g.cells * sizeof(float)));
+    ok = ok && (P.nn_in = (float*)dev_alloc(e, nq * (size_t)e->g.planes * (size_t)e->g.cells * sizeof(float)));
+    ok = ok && (P.nn_dense = (float*)dev_alloc(e, nq * (size_t)e->g.planes * (size_t)e->g.cells * sizeof(float)));
     ok = ok && (P.leaf_count = (uint32_t*)dev_alloc(e, (size_t)P.num_slots * sizeof(uint32_t)));
     ok = ok && (P.leaf_offset = (uint32_t*)dev_alloc(e, (size_t)P.num_slots * sizeof(uint32_t)));
     ok = ok && (e->nn_logits = (float*)dev_alloc(e, nq * (size_t)e->g.A * sizeof(float)));
     ok = ok && (e->nn_value = (float*)dev_alloc(e, nq * sizeof(float)));
     ok = ok && (P.counters = (Counters*)dev_alloc(e, sizeof(Counters)));
+    ok = ok && (P.hist_boards = (uint64_t*)dev_alloc(e, (size_t)P.num_slots * (size_t)e->g.hist_cap * 2 * sizeof(uint64_t)));
     if (!ok) {
         std::string m = std::string("device allocation failed (") + be::last_error() + ")";
         sprl_engine_destroy(e);
@@ -243,8 +252,8 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     }
     P.nn_logits = e->nn_logits;
     P.nn_value = e->nn_value;
-    be::dmemset(P.nn_in, 0, nq * 3 * (size_t)e->g.cells * sizeof(float));
-    be::dmemset(P.nn_dense, 0, nq * 3 * (size_t)e->g.cells * sizeof(float));
+    be::dmemset(P.nn_in, 0, nq * (size_t)e->g.planes * (size_t)e->g.cells * sizeof(float));
+    be::dmemset(P.nn_dense, 0, nq * (size_t)e->g.planes * (size_t)e->g.cells * sizeof(float));
     be::dmemset(P.leaf_count, 0, (size_t)P.num_slots * sizeof(uint32_t));
     be::dmemset(P.leaf_offset, 0, (size_t)P.num_slots * sizeof(uint32_t));
     be::dmemset(e->nn_logits, 0, nq * (size_t)e->g.A * sizeof(float));
@@ -291,7 +300,7 @@ int sprl_engine_set_model(sprl_engine* e, const char* model) {
         int b = rows < max_rows ? rows : max_rows;
         if (b == last) break;
         last = b;
-        if (e->torch.forward(m, e->P.nn_dense, b, 3, e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, err,
+        if (e->torch.forward(m, e->P.nn_dense, b, e->g.planes, e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, err,
                              (int)sizeof(err)) != 0)
             return fail(SPRL_E_MODEL, std::string("network warm-up forward failed: ") + err);
         if (b == max_rows) break;
@@ -362,7 +371,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
     const int launches = net ? rounds : 1;
     P.rounds = net ? 1 : rounds;
     const int max_batch_rows = P.num_slots * P.max_queue;
-    const int floats_per_leaf = 3 * e->g.cells;
+    const int floats_per_leaf = e->g.planes * e->g.cells;
     Counters c;
     memset(&c, 0, sizeof(c));
     for (int r = 0; r < launches; ++r) {
@@ -392,7 +401,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
                     rc = e->forward_cb(e->forward_user, P.nn_dense, batch, e->nn_logits, e->nn_value);
                     if (rc) snprintf(err, sizeof(err), "forward callback returned %d", rc);
                 } else {
-                    rc = e->torch.forward(e->torch_model, P.nn_dense, batch, 3, e->g.rows, e->g.cols, e->nn_logits,
+                    rc = e->torch.forward(e->torch_model, P.nn_dense, batch, e->g.planes, e->g.rows, e->g.cols, e->nn_logits,
                                           e->g.A, e->nn_value, err, (int)sizeof(err));
                 }
                 if (rc) {
@@ -474,6 +483,8 @@ int sprl_engine_collect(sprl_engine* e, sprl_records* out) {
     out->actions = g.A;
     out->nsym = g.nsym;
     out->use_symmetry = e->cfg.use_symmetry ? 1 : 0;
+    out->history = g.hist;
+    out->planes = g.planes;
     out->total_plies = total;
     out->ply_offset = o->ply_offset.data();
     out->boards = o->boards.data();
@@ -553,39 +564,48 @@ int64_t sprl_records_num_samples(const sprl_records* r) {
 }
 
 int sprl_records_expand_boards(const sprl_records* r, int8_t* boards, int8_t* players) {
+    // boards: [N][history][cells]; plies before the start of the game are written as -2 (undefined in the reference)
     if (!r || !boards || !players) return fail(SPRL_E_CONFIG, "null argument");
     const int ns = r->use_symmetry ? r->nsym : 1;
-    for (int64_t p = 0; p < r->total_plies; ++p)
-        for (int s = 0; s < ns; ++s) {
-            int8_t* out = boards + (size_t)(p * ns + s) * (size_t)r->cells;
-            const int8_t* in = r->boards + (size_t)p * (size_t)r->cells;
-            for (int c = 0; c < r->cells; ++c) out[map_cell(r->game, s, c)] = in[c];
-            players[p * ns + s] = r->movers[p];
-        }
+    const int H = r->history, cells = r->cells;
+    for (int gi = 0; gi < r->num_games; ++gi)
+        for (int p = r->ply_offset[gi]; p < r->ply_offset[gi + 1]; ++p)
+            for (int s = 0; s < ns; ++s) {
+                int8_t* out = boards + ((size_t)p * ns + s) * (size_t)H * (size_t)cells;
+                memset(out, -2, (size_t)H * (size_t)cells);
+                for (int t = 0; t < H && p - t >= r->ply_offset[gi]; ++t) {
+                    const int8_t* in = r->boards + (size_t)(p - t) * (size_t)cells;
+                    for (int c = 0; c < cells; ++c) out[(size_t)t * cells + map_cell(r->game, s, c)] = in[c];
+                }
+                players[(size_t)p * ns + s] = r->movers[p];
+            }
     return 0;
 }
 
 int sprl_records_expand(const sprl_records* r, float* states, float* distributions, float* outcomes) {
     if (!r || !states || !distributions || !outcomes) return fail(SPRL_E_CONFIG, "null argument");
     const int ns = r->use_symmetry ? r->nsym : 1;
-    const int cells = r->cells, A = r->actions;
+    const int cells = r->cells, A = r->actions, H = r->history, PL = r->planes;
     for (int gi = 0; gi < r->num_games; ++gi) {
         const int8_t w = r->winners[gi];
         for (int p = r->ply_offset[gi]; p < r->ply_offset[gi + 1]; ++p) {
             const int8_t mover = r->movers[p];
-            const int8_t* in = r->boards + (size_t)p * (size_t)cells;
             const float* pdf = r->pdfs + (size_t)p * (size_t)A;
             const float reward = w < 0 ? 0.0f : (w == mover ? 1.0f : -1.0f);   // OthelloNode.cpp:94-100
             for (int s = 0; s < ns; ++s) {
                 const size_t n = (size_t)p * (size_t)ns + (size_t)s;
-                float* st = states + n * 3 * (size_t)cells;
+                float* st = states + n * (size_t)PL * (size_t)cells;
                 float* di = distributions + n * (size_t)A;
-                for (int c = 0; c < cells; ++c) {
-                    const int t = map_cell(r->game, s, c);
-                    st[t] = in[c] == mover ? 1.0f : 0.0f;                       // own plane
-                    st[cells + t] = (in[c] >= 0 && in[c] != mover) ? 1.0f : 0.0f;  // opponent plane
-                    st[2 * cells + t] = mover == 0 ? 1.0f : 0.0f;               // colour plane
+                memset(st, 0, (size_t)PL * (size_t)cells * sizeof(float));       // missing history = zero planes
+                for (int t = 0; t < H && p - t >= r->ply_offset[gi]; ++t) {       // GridWorker.hpp:152-166
+                    const int8_t* in = r->boards + (size_t)(p - t) * (size_t)cells;
+                    for (int c = 0; c < cells; ++c) {
+                        const int tc = map_cell(r->game, s, c);
+                        if (in[c] == mover) st[(size_t)(2 * t) * cells + tc] = 1.0f;
+                        else if (in[c] >= 0) st[(size_t)(2 * t + 1) * cells + tc] = 1.0f;
+                    }
                 }
+                for (int c = 0; c < cells; ++c) st[(size_t)(2 * H) * cells + c] = mover == 0 ? 1.0f : 0.0f;   // colour plane
                 for (int a = 0; a < A; ++a) di[map_action(r->game, s, a)] = pdf[a];
                 outcomes[n] = reward;
             }
@@ -637,13 +657,13 @@ static int write_npy_f32(const std::string& path, const float* data, const std::
 int sprl_write_npy(const char* path_prefix, const sprl_records* r) {
     if (!path_prefix || !r) return fail(SPRL_E_CONFIG, "null argument");
     const int64_t n = sprl_records_num_samples(r);
-    std::vector<float> states((size_t)n * 3 * (size_t)r->cells), dists((size_t)n * (size_t)r->actions), outs((size_t)n);
+    std::vector<float> states((size_t)n * (size_t)r->planes * (size_t)r->cells), dists((size_t)n * (size_t)r->actions), outs((size_t)n);
     int rc = sprl_records_expand(r, states.data(), dists.data(), outs.data());
     if (rc) return rc;
     std::string p(path_prefix);
     // controller polls for all three files (scripts/othello_controller.py:83-93): outcomes goes last, each
     // file appears atomically
-    if (write_npy_f32(p + "_states.npy", states.data(), { (uint64_t)n, 3, (uint64_t)r->rows, (uint64_t)r->cols }) != 0 ||
+    if (write_npy_f32(p + "_states.npy", states.data(), { (uint64_t)n, (uint64_t)r->planes, (uint64_t)r->rows, (uint64_t)r->cols }) != 0 ||
         write_npy_f32(p + "_distributions.npy", dists.data(), { (uint64_t)n, (uint64_t)r->actions }) != 0 ||
         write_npy_f32(p + "_outcomes.npy", outs.data(), { (uint64_t)n }) != 0)
         return fail(SPRL_E_IO, "io error: failed to open a file.");

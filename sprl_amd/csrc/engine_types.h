@@ -23,7 +23,6 @@
 #define SPRL_ROW 64
 #define SPRL_NONE16 0xFFFFu
 #define SPRL_MAXQ 8
-#define SPRL_PASS 64
 
 enum { F_EVAL = 1, F_TERMINAL = 2, F_PASS = 4 };
 enum { ST_IDLE = 0, ST_ACTIVE = 1, ST_ERROR = 2, ST_FRESH = 3 };
@@ -47,7 +46,8 @@ struct NodeHdr {            // 64 bytes at node + 896
     uint8_t player, flags;
     int8_t winner;
     uint8_t pad0;
-    uint16_t action, pad1;
+    uint16_t action;        // action that led to this node (Go: pass detection for the double-pass end)
+    uint16_t depth;         // plies since the start of the game (Go depth cap)
     uint32_t pad2[2];
 };
 
@@ -75,6 +75,7 @@ struct GameCtl {
     uint32_t leaf_node[SPRL_MAXQ];
     uint32_t leaf_depth[SPRL_MAXQ];
     uint32_t leaf_sym[SPRL_MAXQ];
+    uint32_t leaf_player[SPRL_MAXQ];
     GameStats stats;
 };
 
@@ -108,6 +109,7 @@ struct EngineParams {
     float* nn_dense;        // dense network batch [leaf_total (rounded up)][planes][cells]
     const float* nn_logits;
     const float* nn_value;
+    uint64_t* hist_boards;  // Go: [num_slots][HIST_CAP][2] positions of the real game so far (superko, history planes)
     uint64_t* rec_boards;
     uint8_t* rec_movers;
     float* rec_pdf;

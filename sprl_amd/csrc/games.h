@@ -17,7 +17,7 @@
 #define SPRL_G static inline
 #endif
 
-enum { SPRL_GAME_OTHELLO = 0, SPRL_GAME_CONNECT_FOUR = 1 };
+enum { SPRL_GAME_OTHELLO = 0, SPRL_GAME_CONNECT_FOUR = 1, SPRL_GAME_GO7 = 2 };
 
 struct Pos {
     uint64_t p0, p1;     // stones of Player::ZERO / Player::ONE
@@ -26,6 +26,8 @@ struct Pos {
     uint8_t pass_legal;  // Othello: pass is legal iff nothing else is (OthelloNode.cpp:166-174)
     uint8_t terminal;
     int8_t winner;       // -1 none/draw, 0, 1
+    uint8_t last_pass;   // Go: the action that led here was a pass (GoNode.cpp:359)
+    uint16_t depth;      // Go: plies since the start of the game (GoNode::m_depth)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -37,6 +39,8 @@ struct Othello {
     static constexpr int A = 65;          // 64 placements + pass (OthelloNode.hpp:10)
     static constexpr int NA = 64;         // lane-mapped actions
     static constexpr int HAS_PASS = 1;
+    static constexpr int PASS_EXCLUSIVE = 1;  // pass is legal only when nothing else is
+    static constexpr int HIST = 1, PLANES = 3, HIST_CAP = 1;
     static constexpr int NSYM = 8;        // D4 (symmetry/D4GridSymmetrizer.hpp:30-41)
     static constexpr int MAX_DEPTH = 128; // >= longest possible line (60 placements + interleaved passes)
 
@@ -102,6 +106,8 @@ struct Othello {
         s.p0 = (1ull << (3 * 8 + 4)) | (1ull << (4 * 8 + 3));   // OthelloNode.cpp:26-29
         s.p1 = (1ull << (3 * 8 + 3)) | (1ull << (4 * 8 + 4));
         s.player = 0;
+        s.last_pass = 0;
+        s.depth = 0;
         finish(s);
     }
     SPRL_G void child(const Pos& p, int action, Pos& c) {
@@ -115,6 +121,8 @@ struct Othello {
         c.p0 = p.player ? opp : own;
         c.p1 = p.player ? own : opp;
         c.player = 1 - p.player;
+        c.last_pass = 0;
+        c.depth = 0;
         finish(c);
     }
     // D4 cell maps, out[map(r,c)] = in[r,c] (D4GridSymmetrizer.hpp:108-117)
@@ -145,6 +153,8 @@ struct ConnectFour {
     static constexpr int A = 7;
     static constexpr int NA = 7;
     static constexpr int HAS_PASS = 0;
+    static constexpr int PASS_EXCLUSIVE = 0;
+    static constexpr int HIST = 1, PLANES = 3, HIST_CAP = 1;
     static constexpr int NSYM = 2;        // identity + column mirror (ConnectFourSymmetrizer.cpp:5-13)
     static constexpr int MAX_DEPTH = 64;
 
@@ -156,6 +166,8 @@ struct ConnectFour {
         s.pass_legal = 0;
         s.terminal = 0;
         s.winner = -1;
+        s.last_pass = 0;
+        s.depth = 0;
     }
     SPRL_G int count_dir(uint64_t mine, int r, int c, int dr, int dc) {
         int n = 0;
@@ -178,6 +190,8 @@ struct ConnectFour {
         c.p1 = p.player ? mine : p.p1;
         c.player = 1 - p.player;
         c.pass_legal = 0;
+        c.last_pass = 0;
+        c.depth = 0;
         bool win = 1 + count_dir(mine, row, col, 0, -1) + count_dir(mine, row, col, 0, 1) >= 4 ||
                    1 + count_dir(mine, row, col, -1, 0) + count_dir(mine, row, col, 1, 0) >= 4 ||
                    1 + count_dir(mine, row, col, -1, -1) + count_dir(mine, row, col, 1, 1) >= 4 ||
@@ -194,6 +208,98 @@ struct ConnectFour {
     }
     SPRL_G int map_action(int sym, int a) { return sym == 1 ? 6 - a : a; }
     SPRL_G int inverse_sym(int sym) { return sym; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Go 7x7 (the size the reference compiles: games/GoNode.hpp:16-22), komi 9.0, positional superko, depth cap 98
+// ---------------------------------------------------------------------------------------------
+struct Go7 {
+    static constexpr int ID = SPRL_GAME_GO7;
+    static constexpr int ROWS = 7, COLS = 7, CELLS = 49;
+    static constexpr int A = 50;          // 49 placements + pass (GoNode.hpp:18)
+    static constexpr int NA = 49;
+    static constexpr int HAS_PASS = 1;
+    static constexpr int PASS_EXCLUSIVE = 0;  // pass is always legal and competes in the arg-max (GoNode.cpp:298)
+    static constexpr int HIST = 8, PLANES = 17;
+    static constexpr int GAME_MAX_DEPTH = 98;      // GO_MAX_DEPTH = 2 * 49 (GoNode.hpp:22)
+    static constexpr int HIST_CAP = 104;           // ancestor positions kept per game (>= GAME_MAX_DEPTH + 1)
+    static constexpr int NSYM = 8;
+    static constexpr int MAX_DEPTH = 104;
+
+    static constexpr uint64_t BOARD = (1ull << 49) - 1;
+    static constexpr uint64_t COL0 = 0x0040810204081ull;             // bits r*7 + 0
+    static constexpr uint64_t COL6 = COL0 << 6;
+
+    SPRL_G uint64_t dilate(uint64_t x) {            // the 4-neighbourhood (GoNode.hpp:117-130)
+        return ((x << 7) | (x >> 7) | ((x & ~COL6) << 1) | ((x & ~COL0) >> 1)) & BOARD;
+    }
+    SPRL_G uint64_t flood(uint64_t seed, uint64_t within) {
+        uint64_t g = seed & within;
+        for (;;) {
+            uint64_t n = (g | dilate(g)) & within;
+            if (n == g) return g;
+            g = n;
+        }
+    }
+    SPRL_G void start(Pos& s) {                     // GoNode.cpp:303-317
+        s.p0 = s.p1 = 0;
+        s.player = 0;
+        s.legal = BOARD;
+        s.pass_legal = 1;
+        s.terminal = 0;
+        s.winner = -1;
+        s.last_pass = 0;
+        s.depth = 0;
+    }
+    // Board after `action` by p.player: place, then remove every adjacent enemy group left without liberties
+    // (placePiece phase two, GoNode.cpp:139-169).  The move is legal by construction, so no suicide handling.
+    SPRL_G void apply(const Pos& p, int action, Pos& c) {
+        uint64_t own = p.player ? p.p1 : p.p0, opp = p.player ? p.p0 : p.p1;
+        if (action != 49) {
+            const uint64_t mv = 1ull << action;
+            own |= mv;
+            uint64_t adj = dilate(mv) & opp;
+            while (adj) {
+                uint64_t g = flood(adj & (0 - adj), opp);
+                if ((dilate(g) & ~(own | opp) & BOARD) == 0) opp &= ~g;
+                adj &= ~g;
+            }
+        }
+        c.p0 = p.player ? opp : own;
+        c.p1 = p.player ? own : opp;
+        c.player = 1 - p.player;
+        c.depth = (uint16_t)(p.depth + 1);
+        c.last_pass = action == 49;
+        c.terminal = (p.last_pass && action == 49) || c.depth >= GAME_MAX_DEPTH;    // GoNode.cpp:359-360
+        c.winner = -1;
+        c.legal = 0;
+        c.pass_legal = c.terminal ? 0 : 1;
+        if (c.terminal) {                                                          // Tromp-Taylor, GoNode.cpp:230-290,367-379
+            const uint64_t empty = ~(c.p0 | c.p1) & BOARD;
+            const uint64_t e0 = flood(dilate(c.p0) & empty, empty), e1 = flood(dilate(c.p1) & empty, empty);
+            float s0 = (float)(__builtin_popcountll(c.p0) + __builtin_popcountll(e0 & ~e1));
+            float s1 = (float)(__builtin_popcountll(c.p1) + __builtin_popcountll(e1 & ~e0));
+            s1 += 9.0f;                                                            // GO_KOMI
+            if ((double)s0 > (double)s1 + 0.1) c.winner = 0;
+            else if ((double)s1 > (double)s0 + 0.1) c.winner = 1;
+        }
+    }
+    SPRL_G int map_cell(int sym, int cell) {
+        int r = cell / 7, c = cell % 7, tr, tc;
+        switch (sym) {
+        case 0: tr = r; tc = c; break;
+        case 1: tr = c; tc = 6 - r; break;
+        case 2: tr = 6 - r; tc = 6 - c; break;
+        case 3: tr = 6 - c; tc = r; break;
+        case 4: tr = r; tc = 6 - c; break;
+        case 5: tr = 6 - c; tc = 6 - r; break;
+        case 6: tr = 6 - r; tc = c; break;
+        default: tr = c; tc = r; break;
+        }
+        return tr * 7 + tc;
+    }
+    SPRL_G int map_action(int sym, int a) { return a == 49 ? 49 : map_cell(sym, a); }
+    SPRL_G int inverse_sym(int sym) { return sym == 1 ? 3 : (sym == 3 ? 1 : sym); }
 };
 
 #endif  // SPRL_GAMES_H

@@ -57,6 +57,18 @@ SPRL_DEV NodeHdr load_hdr(uint8_t* n) {
     return h;
 }
 
+#define PASS_A (G::A - 1)      // index of the pass action in games that have one (Othello 64, Go 49)
+
+// per-wavefront LDS: the descent path, and for Go the positions of all ancestors (game start .. current node)
+// for the positional-superko test plus the 8-ply histories of the leaves queued for the network
+template <class G>
+struct WaveLds {
+    uint32_t path[G::MAX_DEPTH];
+    uint64_t hist[G::HIST_CAP][2];
+    uint64_t leaf_hist[SPRL_MAXQ][G::HIST][2];
+    uint32_t leaf_size[SPRL_MAXQ];
+};
+
 struct Game {                 // per-wave working state (wave-uniform values)
     Pcg32 rng;
     uint8_t* abase;
@@ -98,9 +110,11 @@ SPRL_DEV void write_new_node(uint8_t* np, const Pos& s, int action) {
     h->flags = (uint8_t)((s.terminal ? F_TERMINAL : 0) | (s.pass_legal ? F_PASS : 0));
     h->winner = s.winner;
     h->action = (uint16_t)action;
+    h->depth = s.depth;
     rowC(np)[wv::lane()] = SPRL_NONE16;
 }
 
+template <class G>
 SPRL_DEV Pos pos_of(const NodeHdr& h) {
     Pos s;
     s.p0 = h.p0;
@@ -110,6 +124,8 @@ SPRL_DEV Pos pos_of(const NodeHdr& h) {
     s.pass_legal = (h.flags & F_PASS) ? 1 : 0;
     s.terminal = (h.flags & F_TERMINAL) ? 1 : 0;
     s.winner = h.winner;
+    s.last_pass = G::HAS_PASS && h.action == PASS_A && h.depth > 0;
+    s.depth = h.depth;
     return s;
 }
 
@@ -117,6 +133,71 @@ SPRL_DEV Pos pos_of(const NodeHdr& h) {
 // expand (UCTNode::expand, uct/UCTNode.hpp:312-348).  The P row already holds the cached, legal-masked
 // network policy; N and W rows are (re)initialised here, which is what EdgeStatistics::reset() left behind.
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// Go: legal mask of a position, lane <-> point (GoNode::checkLegalPlacement / computeActionMask,
+// games/GoNode.cpp:178-228,292-301).  Every stone lane flood-fills its own group as a bit mask (all lanes in
+// lockstep, wave-uniform trip count), liberties are one popcount, an empty point then looks at its four
+// neighbours' (colour, liberties, group mask) through cross-lane reads, builds the position that placing there
+// would give (captures = adjacent enemy groups in atari) and compares it with every ancestor position kept in
+// LDS — an exact positional-superko test where the reference compares 64-bit Zobrist hashes.
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV uint64_t go_legal_mask(const Pos& c, const uint64_t (*hist)[2], int n_hist) {
+    const int l = wv::lane();
+    const uint64_t own = c.player ? c.p1 : c.p0, opp = c.player ? c.p0 : c.p1;
+    const uint64_t empty = ~(own | opp) & G::BOARD;
+    const uint64_t bit = l < G::CELLS ? (1ull << l) : 0ull;
+    const bool is_own = (own & bit) != 0, is_opp = (opp & bit) != 0, is_empty = (empty & bit) != 0;
+    const uint64_t within = is_own ? own : (is_opp ? opp : 0ull);
+    uint64_t gm = bit & within;
+    for (;;) {
+        const uint64_t n = (gm | G::dilate(gm)) & within;
+        const bool changed = n != gm;
+        gm = n;
+        if (wv::ballot(changed) == 0) break;
+    }
+    const uint32_t libs = (uint32_t)wv::popc64(G::dilate(gm) & empty);
+    const int row = l / G::COLS, col = l % G::COLS;
+    bool has_libs = false;
+    uint64_t cap = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const bool valid = l < G::CELLS && (d == 0 ? row > 0 : d == 1 ? col > 0 : d == 2 ? row < G::ROWS - 1 : col < G::COLS - 1);
+        const int nb = valid ? (d == 0 ? l - G::COLS : d == 1 ? l - 1 : d == 2 ? l + G::COLS : l + 1) : l;
+        const uint32_t nlibs = wv::shfl_u32(libs, nb);
+        const uint32_t glo = wv::shfl_u32((uint32_t)gm, nb), ghi = wv::shfl_u32((uint32_t)(gm >> 32), nb);
+        if (valid) {
+            const uint64_t nbit = 1ull << nb;
+            if (empty & nbit) has_libs = true;
+            else if (own & nbit) { if (nlibs > 1) has_libs = true; }
+            else if (nlibs == 1) { has_libs = true; cap |= ((uint64_t)ghi << 32) | glo; }
+        }
+    }
+    const uint64_t nown = own | bit, nopp = opp & ~cap;
+    const uint64_t np0 = c.player ? nopp : nown, np1 = c.player ? nown : nopp;
+    bool repeat = false;
+    for (int i = 0; i < n_hist; ++i) repeat |= (hist[i][0] == np0) && (hist[i][1] == np1);
+    return wv::ballot(is_empty && has_libs && !repeat);
+}
+
+// GameNode::getAddChild -> getNextNodeImpl for every game; `depth` = tree depth of the parent
+template <class G>
+SPRL_DEV void make_child(const EngineParams& P, Game& g, WaveLds<G>* lds, const Pos& parent, int action, int at,
+                         Pos& cs) {
+    // `at` = the child's index among the ancestor positions (game ply of the root + tree depth of the child)
+    if constexpr (G::ID == SPRL_GAME_GO7) {
+        G::apply(parent, action, cs);
+        if (wv::lane() == 0) {
+            lds->hist[at][0] = cs.p0;
+            lds->hist[at][1] = cs.p1;
+        }
+        wv::sync();
+        if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds->hist, at + 1);
+    } else {
+        G::child(parent, action, cs);
+    }
+}
+
 // Dirichlet root noise (UCTNode.hpp:330-347): rare (once per move) and heavy (serial gamma draws in double
 // arithmetic), so it is kept out of line to keep the descent loop's code and register footprint small.
 template <class G>
@@ -185,7 +266,7 @@ SPRL_DEV void backup_path(Game& g, uint32_t my_entry0, uint32_t my_entry1, int d
             const int child_player = (int)(g.root_player ^ ((uint32_t)(j + 1) & 1u));
             const float add = 1.0f + est * (child_player == 0 ? 1.0f : -1.0f);
             uint8_t* np = node_at(g.abase, node);
-            float* wp = (G::HAS_PASS && a == SPRL_PASS) ? &hdr_of(np)->passW : &rowW(np)[a];
+            float* wp = (G::HAS_PASS && a == PASS_A) ? &hdr_of(np)->passW : &rowW(np)[a];
             *wp = *wp + add;
         }
     }
@@ -256,17 +337,23 @@ SPRL_DEV void evaluate_leaf(const EngineParams& P, Game& g, uint8_t* np, NodeHdr
     h->flags = hc.flags;
 }
 
-// symmetrised input planes of a queued leaf (GridNetwork.hpp:72-97 after D4GridSymmetrizer.hpp:52-75)
+// symmetrised input planes of a queued leaf (GridNetwork.hpp:72-97 after D4GridSymmetrizer.hpp:52-75): plane 2t / 2t+1 =
+// stones of the side to move / the opponent t plies ago (t < size, else zero), last plane = colour to move
 template <class G>
-SPRL_DEV void encode_leaf(const EngineParams& P, const NodeHdr& h, int sym, int nn_slot) {
+SPRL_DEV void encode_leaf(const EngineParams& P, const WaveLds<G>* lds, int q, int player, int sym, int nn_slot) {
     const int l = wv::lane();
     if (l < G::CELLS) {
         const int src = G::map_cell(G::inverse_sym(sym), l);      // out[map_s(i)] = in[i]
-        const uint64_t own = h.player ? h.p1 : h.p0, opp = h.player ? h.p0 : h.p1;
-        float* out = P.nn_in + (size_t)nn_slot * (3 * G::CELLS);
-        out[l] = (float)((own >> src) & 1ull);
-        out[G::CELLS + l] = (float)((opp >> src) & 1ull);
-        out[2 * G::CELLS + l] = h.player == 0 ? 1.0f : 0.0f;
+        float* out = P.nn_in + (size_t)nn_slot * (G::PLANES * G::CELLS);
+        const int size = (int)lds->leaf_size[q];
+#pragma unroll
+        for (int t = 0; t < G::HIST; ++t) {
+            const uint64_t p0 = lds->leaf_hist[q][t][0], p1 = lds->leaf_hist[q][t][1];
+            const uint64_t own = player ? p1 : p0, opp = player ? p0 : p1;
+            out[(2 * t) * G::CELLS + l] = t < size ? (float)((own >> src) & 1ull) : 0.0f;
+            out[(2 * t + 1) * G::CELLS + l] = t < size ? (float)((opp >> src) & 1ull) : 0.0f;
+        }
+        out[(2 * G::HIST) * G::CELLS + l] = player == 0 ? 1.0f : 0.0f;
     }
 }
 
@@ -310,7 +397,8 @@ SPRL_DEV void finish_leaves(const EngineParams& P, Game& g, int slot, GameCtl* c
 // select: UCTTree::searchAndGetLeaves
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ctl, uint32_t* lds_path) {
+SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ctl, WaveLds<G>* lds) {
+    uint32_t* lds_path = lds->path;
     const int l = wv::lane();
     int trav = 0;
     while (trav < P.max_batch) {
@@ -326,12 +414,30 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         float n, w, p;
         uint32_t ch;
         load_node(node_at(g.abase, cur), h, n, w, p, ch);
+        if (G::HIST_CAP > 1 && l == 0) {                   // ancestors: entry ply + d = node at tree depth d
+            lds->hist[g.ply][0] = h.p0;
+            lds->hist[g.ply][1] = h.p1;
+        }
         while (h.exp_epoch == g.epoch && !(h.flags & F_TERMINAL)) {
             uint8_t* np = node_at(g.abase, cur);
             int a;
-            if (G::HAS_PASS && h.legal == 0) {             // pass is the only legal action (mask[64] only)
+            if (G::HAS_PASS && G::PASS_EXCLUSIVE && h.legal == 0) {   // pass is the only legal action (mask[64] only)
                 (void)rng_uniform_int(g.rng, 1u);           // bestAction still draws (UCTNode.hpp:250)
-                a = SPRL_PASS;
+                a = PASS_A;
+            } else if (G::HAS_PASS && !G::PASS_EXCLUSIVE) {  // Go: pass (last index) competes with the placements
+                const bool lg = l < G::NA && ((h.legal >> l) & 1ull);
+                const float sq = __builtin_sqrtf(nself);
+                const float den = 1.0f + n;
+                const float score = w / den + P.u_weight * (p * sq / den);
+                const float pden = 1.0f + h.passN;
+                const float pscore = h.passW / pden + P.u_weight * (h.passP * sq / pden);
+                float best = wv::fmax_all(lg ? score : -__builtin_inff());
+                best = pscore > best ? pscore : best;
+                const uint64_t ties = wv::ballot(lg && score == best);
+                const int kb = wv::popc64(ties);
+                const int k = kb + (pscore == best ? 1 : 0);
+                const int r = rng_uniform_int(g.rng, (uint32_t)k);
+                a = r < kb ? wv::nth_set_bit(ties, r) : PASS_A;
             } else {
                 const bool lg = l < G::NA && ((h.legal >> l) & 1ull);
                 const float sq = __builtin_sqrtf(nself);
@@ -353,7 +459,7 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
             NodeHdr* hp = hdr_of(np);
             uint32_t c;
             float n_a, w_a;
-            if (G::HAS_PASS && a == SPRL_PASS) {
+            if (G::HAS_PASS && a == PASS_A) {
                 c = h.passChild;
                 n_a = h.passN;
                 w_a = h.passW;
@@ -368,15 +474,15 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
                 SPRL_TIC(t_cr);
                 c = g.n_alloc++;
                 created = true;
-                G::child(pos_of(h), a, cs);
+                make_child<G>(P, g, lds, pos_of<G>(h), a, g.ply + depth, cs);
                 write_new_node<G>(node_at(g.abase, c), cs, a);
                 SPRL_TOC(g.cyc_create, t_cr);
                 w_a = h.value;                              // InitQ::PARENT (UCTNode.hpp:271-273)
                 g.d_created++;
-                if (G::HAS_PASS && a == SPRL_PASS) hp->passChild = c;
+                if (G::HAS_PASS && a == PASS_A) hp->passChild = c;
                 else if (l == a) rowC(np)[l] = (uint16_t)c;
             }
-            if (G::HAS_PASS && a == SPRL_PASS) {
+            if (G::HAS_PASS && a == PASS_A) {
                 hp->passN = n_a + 1.0f;
                 hp->passW = w_a - 1.0f;
             } else if (l == a) {
@@ -389,10 +495,15 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
                 // a freshly created node is empty: header known without reloading it
                 h.p0 = cs.p0; h.p1 = cs.p1; h.legal = cs.legal; h.value = 0.0f; h.exp_epoch = 0;
                 h.passChild = SPRL_NONE16; h.player = cs.player; h.winner = cs.winner;
+                h.action = (uint16_t)a; h.depth = cs.depth;
                 h.flags = (uint8_t)((cs.terminal ? F_TERMINAL : 0) | (cs.pass_legal ? F_PASS : 0));
                 break;
             }
             load_node(node_at(g.abase, cur), h, n, w, p, ch);
+            if (G::HIST_CAP > 1 && l == 0) {
+                lds->hist[g.ply + depth][0] = h.p0;
+                lds->hist[g.ply + depth][1] = h.p1;
+            }
         }
         // ---- leaf handling (UCTTree.hpp:87-110) ----
         if (h.flags & F_TERMINAL) {
@@ -416,6 +527,16 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
             uint32_t* path = P.paths + ((size_t)slot * SPRL_MAXQ + q) * P.max_depth;
             if (l < depth) path[l] = lds_path[l];
             if (64 + l < depth) path[64 + l] = lds_path[64 + l];
+            // the leaf's own position and up to HIST-1 ancestors, newest first (GoNode.cpp:385-398)
+            const int last = g.ply + depth;
+            const int size = G::HIST_CAP > 1 ? (last + 1 < G::HIST ? last + 1 : G::HIST) : 1;
+            wv::sync();
+            if (l < size) {
+                lds->leaf_hist[q][l][0] = G::HIST_CAP > 1 ? lds->hist[last - l][0] : h.p0;
+                lds->leaf_hist[q][l][1] = G::HIST_CAP > 1 ? lds->hist[last - l][1] : h.p1;
+            }
+            if (l == 0) lds->leaf_size[q] = (uint32_t)size;
+            ctl->leaf_player[q] = h.player;
         }
         if (g.n_leaves >= P.max_queue) break;
     }
@@ -428,8 +549,8 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         if (P.use_sym) sym = rng_uniform_int(g.rng, (uint32_t)G::NSYM);
         ctl->leaf_sym[q] = (uint32_t)sym;
         if (P.eval_kind == EVAL_NETWORK) {
-            NodeHdr lh = load_hdr(node_at(g.abase, ctl->leaf_node[q]));
-            encode_leaf<G>(P, lh, sym, slot * P.max_queue + q);
+            wv::sync();
+            encode_leaf<G>(P, lds, q, (int)ctl->leaf_player[q], sym, slot * P.max_queue + q);
         }
     }
     g.d_nn_evals += (uint32_t)g.n_leaves;
@@ -503,7 +624,7 @@ SPRL_DEV_NOINLINE bool compact_arena(const EngineParams& P, Game& g) {
 // new game / move
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV_NOINLINE void start_game(const EngineParams& P, Game& g) {
+SPRL_DEV_NOINLINE void start_game(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds) {
     uint32_t gid = 0;
     if (wv::lane() == 0) gid = wv::atomic_add_u32(&P.counters->next_game, 1u);
     gid = wv::bcast_u32(gid, 0);
@@ -527,11 +648,20 @@ SPRL_DEV_NOINLINE void start_game(const EngineParams& P, Game& g) {
     g.traversals = 0;
     g.n_leaves = 0;
     g.d_created++;
+    if (G::HIST_CAP > 1) {
+        if (wv::lane() == 0) {
+            lds->hist[0][0] = s.p0;
+            lds->hist[0][1] = s.p1;
+        }
+        uint64_t* gh = P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
+        gh[0] = s.p0;
+        gh[1] = s.p1;
+    }
 }
 
 // SelfPlay.hpp:110-148: visit pdf, temperature, CDF sample, record, re-root
 template <class G>
-SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g) {
+SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds) {
     const int l = wv::lane();
     uint8_t* np = node_at(g.abase, g.root);
     const NodeHdr hcopy = load_hdr(np);
@@ -585,7 +715,7 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g) {
     // N()/W() (Q6), bump the epoch (== clearSubtree), forget the siblings (== pruneChildrenExcept).
     uint32_t c;
     float n_a, w_a;
-    if (G::HAS_PASS && action == SPRL_PASS) {
+    if (G::HAS_PASS && action == PASS_A) {
         c = h->passChild;
         n_a = h->passN;
         w_a = h->passW;
@@ -596,7 +726,7 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g) {
     }
     if (c == SPRL_NONE16) {                   // cannot happen for a sampled action (visits > 0); kept for safety
         Pos cs;
-        G::child(pos_of(*h), action, cs);
+        make_child<G>(P, g, lds, pos_of<G>(*h), action, g.ply + 1, cs);
         c = g.n_alloc++;
         write_new_node<G>(node_at(g.abase, c), cs, action);
         w_a = (h->flags & F_EVAL) ? h->value : 0.0f;
@@ -606,6 +736,16 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g) {
     g.rootW = w_a;
     g.root_player ^= 1u;
     g.ply += 1;
+    if (G::HIST_CAP > 1) {                     // the new decision node's position joins the real-game history
+        const NodeHdr nh = load_hdr(node_at(g.abase, c));
+        if (l == 0) {
+            lds->hist[g.ply][0] = nh.p0;
+            lds->hist[g.ply][1] = nh.p1;
+        }
+        uint64_t* gh = P.hist_boards + ((size_t)slot * G::HIST_CAP + (size_t)g.ply) * 2;
+        gh[0] = nh.p0;
+        gh[1] = nh.p1;
+    }
     g.epoch += 1;
     g.traversals = 0;
     g.d_plies++;
@@ -615,7 +755,7 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g) {
 // one game slot, up to P.rounds rounds
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
+SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
     GameCtl* ctl = P.ctl + slot;
     Game g;
     g.status = ctl->status;
@@ -642,14 +782,22 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
     wv::sync();
 
     SPRL_TIC(t_all);
-    if (g.status == ST_FRESH) start_game<G>(P, g);
+    if (G::HIST_CAP > 1 && g.status == ST_ACTIVE) {          // real-game positions 0..ply back into LDS
+        const uint64_t* gh = P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
+        for (int i = wv::lane(); i <= g.ply; i += 64) {
+            lds->hist[i][0] = gh[2 * i];
+            lds->hist[i][1] = gh[2 * i + 1];
+        }
+        wv::sync();
+    }
+    if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);
 
     for (int round = 0; round < P.rounds && g.status == ST_ACTIVE; ++round) {
         { SPRL_TIC(t_f); if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl); SPRL_TOC(g.cyc_finish, t_f); }
         // while (traversals < numTraversals) ... ; then the move; then the next ply's search begins
         bool idle = false;
         while (g.traversals >= P.num_traversals) {
-            { SPRL_TIC(t_m); play_move<G>(P, g); SPRL_TOC(g.cyc_move, t_m); }
+            { SPRL_TIC(t_m); play_move<G>(P, g, slot, lds); SPRL_TOC(g.cyc_move, t_m); }
             if (g.status != ST_ACTIVE) break;
             const NodeHdr rh = load_hdr(node_at(g.abase, g.root));
             if (rh.flags & F_TERMINAL) {                          // SelfPlay.hpp:85,151
@@ -657,7 +805,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
                 P.rec_winner[g.game_id] = rh.winner;
                 g.d_games++;
                 if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
-                start_game<G>(P, g);
+                start_game<G>(P, g, slot, lds);
                 if (g.status != ST_ACTIVE) { idle = true; break; }
             }
         }
@@ -666,7 +814,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, uint32_t* lds_path) {
             if (!compact_arena<G>(P, g)) break;
             if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
         }
-        { SPRL_TIC(t_s); select_batch<G>(P, g, slot, ctl, lds_path); SPRL_TOC(g.cyc_select, t_s); }
+        { SPRL_TIC(t_s); select_batch<G>(P, g, slot, ctl, lds); SPRL_TOC(g.cyc_select, t_s); }
     }
 
     ctl->status = g.status;

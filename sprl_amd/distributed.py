@@ -13,7 +13,7 @@ def pack_records(rec):
     cells[:, :rec.cells] = rec.boards
     b0 = np.packbits(cells == 0, axis=1, bitorder="little")           # [n, 8]
     b1 = np.packbits(cells == 1, axis=1, bitorder="little")
-    head = np.array([g, n, A, rec.cells, rec.game, rec.nsym, int(rec.use_symmetry), rec.rows, rec.cols], np.int64)
+    head = np.array([g, n, A, rec.cells, rec.game, rec.nsym, int(rec.use_symmetry), rec.rows, rec.cols], np.int64)  # 9 x int64
     parts = [head.view(np.uint8), rec.ply_offset.astype(np.int32).view(np.uint8), rec.winners.view(np.uint8),
              b0.reshape(-1), b1.reshape(-1), rec.movers.view(np.uint8),
              np.ascontiguousarray(rec.pdfs, np.float32).view(np.uint8).reshape(-1)]

@@ -12,10 +12,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libsprl_amd.so")
 
-OTHELLO, CONNECT_FOUR = 0, 1
+OTHELLO, CONNECT_FOUR, GO7 = 0, 1, 2
 EVAL_RANDOM, EVAL_HEURISTIC, EVAL_NETWORK = 0, 1, 2
 MASK_REFERENCE, MASK_SYMMETRISED = 0, 1
-GAME_IDS = {"othello": OTHELLO, "connect_four": CONNECT_FOUR, "c4": CONNECT_FOUR}
+GAME_IDS = {"othello": OTHELLO, "connect_four": CONNECT_FOUR, "c4": CONNECT_FOUR, "go": GO7, "go7": GO7}
 
 
 class SprlError(RuntimeError):
@@ -39,7 +39,7 @@ class Records(C.Structure):
     _fields_ = [
         ("game", C.c_int32), ("num_games", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
         ("cells", C.c_int32), ("actions", C.c_int32), ("nsym", C.c_int32), ("use_symmetry", C.c_int32),
-        ("total_plies", C.c_int64), ("ply_offset", C.POINTER(C.c_int32)), ("boards", C.POINTER(C.c_int8)),
+        ("history", C.c_int32), ("planes", C.c_int32), ("total_plies", C.c_int64), ("ply_offset", C.POINTER(C.c_int32)), ("boards", C.POINTER(C.c_int8)),
         ("movers", C.POINTER(C.c_int8)), ("pdfs", C.POINTER(C.c_float)), ("winners", C.POINTER(C.c_int8)),
         ("owner_", C.c_void_p),
     ]
@@ -137,6 +137,7 @@ class SelfPlayRecords:
         self.game, self.num_games, self.total_plies = r.game, ng, n
         self.rows, self.cols, self.cells, self.actions, self.nsym = r.rows, r.cols, r.cells, r.actions, r.nsym
         self.use_symmetry = bool(r.use_symmetry)
+        self.history, self.planes = r.history, r.planes
         self.ply_offset = np.ctypeslib.as_array(r.ply_offset, shape=(ng + 1,)).copy()
         self.boards = np.ctypeslib.as_array(r.boards, shape=(n, r.cells)).copy()
         self.movers = np.ctypeslib.as_array(r.movers, shape=(n,)).copy()
@@ -148,9 +149,9 @@ class SelfPlayRecords:
         return int(self._lib.sprl_records_num_samples(C.byref(self._rec)))
 
     def expand(self):
-        """(states float32[N,3,R,C], distributions float32[N,A], outcomes float32[N]) — GridWorker.hpp:146-196."""
+        """(states float32[N,2H+1,R,C], distributions float32[N,A], outcomes float32[N]) — GridWorker.hpp:146-196."""
         n = self.num_samples
-        states = np.zeros((n, 3, self.rows, self.cols), np.float32)
+        states = np.zeros((n, self.planes, self.rows, self.cols), np.float32)
         dists = np.zeros((n, self.actions), np.float32)
         outs = np.zeros(n, np.float32)
         rc = self._lib.sprl_records_expand(C.byref(self._rec), states.ctypes.data, dists.ctypes.data, outs.ctypes.data)
@@ -160,7 +161,7 @@ class SelfPlayRecords:
 
     def expand_boards(self):
         n = self.num_samples
-        boards = np.zeros((n, self.cells), np.int8)
+        boards = np.zeros((n, self.history * self.cells), np.int8)
         players = np.zeros(n, np.int8)
         rc = self._lib.sprl_records_expand_boards(C.byref(self._rec), boards.ctypes.data, players.ctypes.data)
         if rc:

@@ -63,6 +63,7 @@ GAME_SHAPES = {
     # game: (rows, cols, actions, history)  — OthelloNode.hpp:8-11, ConnectFourNode.hpp:8-13
     "othello": (8, 8, 65, 1),
     "connect_four": (6, 7, 7, 1),
+    "go7": (7, 7, 50, 8),                 # GoNode.hpp:16-19
 }
 
 

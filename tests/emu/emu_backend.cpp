@@ -17,12 +17,13 @@ void launch(block_fn fn, void* arg, int nblocks);
 }
 
 namespace {
-static thread_local uint32_t tl_lds[256];
+alignas(16) static thread_local unsigned char tl_lds[16384];
 
 template <class G>
 void block_entry(void* arg, int block) {
     const EngineParams* P = (const EngineParams*)arg;
-    sprl::step_game<G>(*P, block, tl_lds);
+    static_assert(sizeof(sprl::WaveLds<G>) <= sizeof(tl_lds), "emulated LDS too small");
+    sprl::step_game<G>(*P, block, reinterpret_cast<sprl::WaveLds<G>*>(tl_lds));
 }
 }  // namespace
 
@@ -40,6 +41,7 @@ int sync() { return 0; }
 int launch_step(int game, const EngineParams& P) {
     EngineParams copy = P;
     if (game == SPRL_GAME_OTHELLO) emu::launch(block_entry<Othello>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO7) emu::launch(block_entry<Go7>, &copy, P.num_slots);
     else emu::launch(block_entry<ConnectFour>, &copy, P.num_slots);
     return 0;
 }

@@ -48,6 +48,39 @@ def test_othello_symmetrised_mask_option(emu):
     parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=30, mask_frame=E.MASK_SYMMETRISED)
 
 
+def test_go7_random(emu):
+    """Go 7x7 as the reference compiles it: pass competes in the arg-max, captures, positional superko against the
+    ancestor positions, double-pass / depth-cap endings, Tromp-Taylor + komi, 8-ply history states."""
+    rec, st = parity.check_case(emu, "go", 3, concurrent_games=2, num_traversals=48)
+    assert rec.history == 8 and rec.planes == 17 and rec.actions == 50
+
+
+def test_go7_compaction_and_batch1(emu):
+    parity.check_case(emu, "go", 2, concurrent_games=2, num_traversals=40, node_cap=150, spare_arenas=2, seed=31)
+    parity.check_case(emu, "go", 1, concurrent_games=1, num_traversals=20, max_batch=1, max_queue=1, use_symmetry=0,
+                      add_noise=0, seed=5)
+
+
+def test_go7_network_path_toy_forward(emu):
+    """17-plane history encoding (symmetrised per ply) -> forward -> decode, against the oracle's GridNetwork restatement."""
+    A = 50
+
+    def engine_forward(planes_ptr, batch, logits_ptr, value_ptr):
+        planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_float)), shape=(batch, 17, 7, 7))
+        lo, va = parity.toy_forward_numpy(planes, A)
+        np.ctypeslib.as_array(C.cast(logits_ptr, C.POINTER(C.c_float)), shape=(batch, A))[:] = lo
+        np.ctypeslib.as_array(C.cast(value_ptr, C.POINTER(C.c_float)), shape=(batch,))[:] = va
+        return 0
+
+    cfg, rec, st = parity.run_engine(emu, "go", 2, forward=engine_forward, concurrent_games=2, num_traversals=24, seed=5)
+    cb = po.make_forward(lambda x: parity.toy_forward_numpy(x, A), po.GAME_GO7)
+    ora = po.selfplay(parity.oracle_config("go", cfg, po.EVAL_CALLBACK, forward=cb), 2, 5, 1, True)
+    parity.assert_same_games(rec, ora)
+    parity.assert_same_counters(st, ora["stats"])
+    states, _, _ = rec.expand()
+    assert states.shape[1:] == (17, 7, 7)
+
+
 def test_more_games_than_slots_and_stream_base(emu):
     rec, st = parity.check_case(emu, "c4", 5, concurrent_games=2, num_traversals=30, seed=99, stream_base=17)
     assert rec.num_games == 5 and st["games"] == 5

@@ -46,6 +46,21 @@ def test_c4_reference_config(lib):
     parity.check_case(lib, "c4", 16, concurrent_games=8, num_traversals=100)
 
 
+def test_go7_whole_games(lib):
+    """Go 7x7 (reference size), GoWorker constants (batch 16 / queue 8, alpha 0.2), 400 traversals/move."""
+    rec, st = parity.check_case(lib, "go", 6, concurrent_games=6, num_traversals=400)
+    assert rec.planes == 17
+
+
+def test_go7_many_games_short_budget(lib):
+    parity.check_case(lib, "go", 128, concurrent_games=128, num_traversals=32, seed=77)
+
+
+def test_go7_compaction(lib):
+    rec, st = parity.check_case(lib, "go", 4, concurrent_games=4, num_traversals=64, node_cap=200, spare_arenas=4)
+    assert st["compactions"] > 0
+
+
 def test_compaction_tiny_arena(lib):
     rec, st = parity.check_case(lib, "othello", 4, concurrent_games=4, num_traversals=60, node_cap=160, spare_arenas=4)
     assert st["compactions"] > 0
