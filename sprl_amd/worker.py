@@ -47,10 +47,12 @@ class WorkerConstants:
     dir_alpha: float
 
 
-# OTHWorker.cpp:12-32, C4Worker.cpp:11-30
+# OTHWorker.cpp:12-32, C4Worker.cpp:11-31
 REFERENCE_WORKERS = {
     "othello": WorkerConstants("othello", "orangutan_alpha", 4, 384, 50, 3, 131072, 1, 1, 3, 8192, 8, 4, 0.25, 0.3),
-    "connect_four": WorkerConstants("connect_four", "panda_gamma", 1, 1, 25, 10, 2048, 1, 1, 5, 512, 8, 4, 0.25, 0.5),
+    "connect_four": WorkerConstants("connect_four", "c4_test", 1, 1, 25, 10, 2048, 1, 1, 5, 512, 8, 4, 0.25, 0.5),
+    # GoWorker.cpp:11-29 (Go as compiled by the reference: 7x7)
+    "go7": WorkerConstants("go7", "panda_alpha", 4, 384, 100, 3, 262144, 1, 1, 3, 32768, 16, 8, 0.25, 0.2),
 }
 
 
