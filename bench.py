@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--node-cap", type=int, default=0, help="nodes per game arena (0 = engine default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N > 1 code path")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -124,12 +127,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no MI355X visible (the engine has no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm_device = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     from sprl_amd import engine as E
     from sprl_amd.network import make_network, trace_to_file
@@ -160,7 +169,7 @@ def main():
         if dist is None:
             return rec.total_plies
         from sprl_amd.distributed import gather_records as _gather
-        shards = _gather(rec, dist, device=torch.device("cuda", local_rank))
+        shards = _gather(rec, dist, device=comm_device)
         torch.cuda.synchronize()
         return sum(sh["total_plies"] for sh in shards) if shards is not None else rec.total_plies
 
@@ -190,7 +199,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st1 = eng.stats()
@@ -234,9 +243,14 @@ def main():
             out["phase_cycles_share"]["total_cycles_per_slot_launch"] = d["cyc_total"] / max(1, d["kernel_launches"]) / args.concurrent
         if not args.no_profile and d["kernel_ms"] > 0:
             achieved = d["traversals"] * bpt / (d["kernel_ms"] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "tree_kernel_traffic.json")
+            if os.path.exists(tpath):           # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
+                with open(tpath) as tf:
+                    traffic = json.load(tf).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "kernel": "step_kernel<Othello> (select/expand/backup/re-root)",
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "bytes_per_traversal": bpt,
                                "avg_launch_ms": d["kernel_ms"] / max(1, d["kernel_launches"]),
                                "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"])}
