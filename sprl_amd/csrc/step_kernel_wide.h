@@ -1,0 +1,812 @@
+// step_kernel_wide.h — the self-play step for boards wider than one wavefront (Go 9x9, 19x19).
+//
+// Same algorithm, same reference semantics and the same one-wavefront-per-game mapping as step_kernel.h, with rows
+// of S = ceil(actions / 64) strips: point / action a lives in strip a / 64, lane a % 64, every row operation loops
+// over the strips, and cross-point reads that can leave the strip (a point's neighbours, the inverse symmetry of a
+// policy) go through a small LDS exchange instead of a single ds_bpermute.  The single-strip kernel stays the tuned
+// path for the benchmark game; this one trades some speed for generality and is checked against the same oracle
+// (including at 7x7, where the oracle is pinned to the reference).
+#ifndef SPRL_STEP_KERNEL_WIDE_H
+#define SPRL_STEP_KERNEL_WIDE_H
+
+#include "dev_rng.h"
+#include "engine_types.h"
+#include "games_wide.h"
+#include "wave.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace sprlw {
+
+template <int W>
+struct NodeHdrW {
+    Bits<W> p0, p1, legal;
+    float value;
+    uint32_t exp_epoch;
+    float passN, passW, passP;
+    uint32_t passChild;
+    uint8_t player, flags;
+    int8_t winner;
+    uint8_t pad0;
+    uint16_t action, depth;
+};
+
+template <class G>
+struct WaveLdsW {
+    uint32_t path[G::MAX_DEPTH];
+    Bits<G::WORDS> hist[G::HIST_CAP][2];
+    Bits<G::WORDS> leaf_hist[SPRL_MAXQ][G::HIST][2];
+    uint32_t leaf_size[SPRL_MAXQ];
+    float xf[G::STRIPS * 64];                 // cross-strip exchange: one float / u32 / group mask per point
+    uint32_t xu[G::STRIPS * 64];
+    Bits<G::WORDS> xg[G::STRIPS * 64];
+};
+
+template <class G> SPRL_DEV uint8_t* node_at(uint8_t* abase, uint32_t idx) { return abase + (size_t)idx * G::NODE_BYTES; }
+template <class G> SPRL_DEV float* rowN(uint8_t* n) { return (float*)n; }
+template <class G> SPRL_DEV float* rowW(uint8_t* n) { return (float*)(n + G::OFF_W); }
+template <class G> SPRL_DEV float* rowP(uint8_t* n) { return (float*)(n + G::OFF_P); }
+template <class G> SPRL_DEV uint16_t* rowC(uint8_t* n) { return (uint16_t*)(n + G::OFF_C); }
+template <class G> SPRL_DEV NodeHdrW<G::WORDS>* hdr_of(uint8_t* n) { return (NodeHdrW<G::WORDS>*)(n + G::OFF_H); }
+
+#define WPASS (G::A - 1)
+#define WS (G::STRIPS)
+
+struct GameW {
+    Pcg32 rng;
+    uint8_t* abase;
+    uint32_t arena, root, n_alloc, epoch, root_player, game_id, status;
+    float rootN, rootW;
+    int ply, traversals, n_leaves;
+    uint32_t d_traversals, d_levels, d_expansions, d_nn_evals, d_terminal, d_gray, d_dup, d_created, d_compactions,
+        d_games, d_plies;
+};
+
+SPRL_DEV void raise_error(const EngineParams& P, GameW& g, uint32_t code) {
+    if (wv::lane() == 0) {
+        if (wv::atomic_cas_u32(&P.counters->error, 0u, code) == 0u) P.counters->error_game = g.game_id;
+    }
+    g.status = ST_ERROR;
+}
+
+template <class G>
+SPRL_DEV NodeHdrW<G::WORDS> load_hdr(uint8_t* n) {
+    NodeHdrW<G::WORDS> h = *hdr_of<G>(n);
+    wv::sync();
+    return h;
+}
+
+template <class G>
+SPRL_DEV void write_new_node(uint8_t* np, const PosW<G::WORDS>& s, int action) {
+    NodeHdrW<G::WORDS>* h = hdr_of<G>(np);
+    h->p0 = s.p0;
+    h->p1 = s.p1;
+    h->legal = s.legal;
+    h->value = 0.0f;
+    h->exp_epoch = 0;
+    h->passN = 0.0f;
+    h->passW = 0.0f;
+    h->passP = 0.0f;
+    h->passChild = SPRL_NONE16;
+    h->player = s.player;
+    h->flags = (uint8_t)((s.terminal ? F_TERMINAL : 0) | (s.pass_legal ? F_PASS : 0));
+    h->winner = s.winner;
+    h->action = (uint16_t)action;
+    h->depth = s.depth;
+    for (int st = 0; st < WS; ++st) rowC<G>(np)[st * 64 + wv::lane()] = SPRL_NONE16;
+}
+
+template <class G>
+SPRL_DEV PosW<G::WORDS> pos_of(const NodeHdrW<G::WORDS>& h) {
+    PosW<G::WORDS> s;
+    s.p0 = h.p0;
+    s.p1 = h.p1;
+    s.legal = h.legal;
+    s.player = h.player;
+    s.pass_legal = (h.flags & F_PASS) ? 1 : 0;
+    s.terminal = (h.flags & F_TERMINAL) ? 1 : 0;
+    s.winner = h.winner;
+    s.last_pass = h.action == WPASS && h.depth > 0;
+    s.depth = h.depth;
+    return s;
+}
+
+// Legal mask of a Go position (GoNode.cpp:178-228,292-301), point a = strip * 64 + lane: per-point group flood fill,
+// liberties, neighbour inspection through the LDS exchange, exact positional-superko compare with the ancestors.
+template <class G>
+SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, int n_hist) {
+    using BB = Bits<G::WORDS>;
+    const int l = wv::lane();
+    const BB own = c.player ? c.p1 : c.p0, opp = c.player ? c.p0 : c.p1;
+    const BB board = G::board_mask();
+    const BB empty = ~(own | opp) & board;
+    BB gm[WS], within[WS];
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        const bool on = a < G::CELLS;
+        const bool is_own = on && own.test(a), is_opp = on && opp.test(a);
+        within[st] = is_own ? own : (is_opp ? opp : BB::zero());
+        gm[st] = on ? (BB::bit(a) & within[st]) : BB::zero();
+    }
+    for (;;) {
+        bool changed = false;
+        for (int st = 0; st < WS; ++st) {
+            const BB n = (gm[st] | G::dilate(gm[st])) & within[st];
+            changed |= n != gm[st];
+            gm[st] = n;
+        }
+        if (wv::ballot(changed) == 0) break;
+    }
+    wv::sync();
+    for (int st = 0; st < WS; ++st) {
+        lds->xu[st * 64 + l] = (uint32_t)(G::dilate(gm[st]) & empty).popc();
+        lds->xg[st * 64 + l] = gm[st];
+    }
+    wv::sync();
+    BB legal = BB::zero();
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        bool ok = false;
+        if (a < G::CELLS && empty.test(a)) {
+            const int row = a / G::COLS, col = a % G::COLS;
+            bool has_libs = false;
+            BB cap = BB::zero();
+            for (int d = 0; d < 4; ++d) {
+                const bool valid = d == 0 ? row > 0 : d == 1 ? col > 0 : d == 2 ? row < G::ROWS - 1 : col < G::COLS - 1;
+                if (!valid) continue;
+                const int nb = d == 0 ? a - G::COLS : d == 1 ? a - 1 : d == 2 ? a + G::COLS : a + 1;
+                if (empty.test(nb)) has_libs = true;
+                else if (own.test(nb)) { if (lds->xu[nb] > 1) has_libs = true; }
+                else if (lds->xu[nb] == 1) { has_libs = true; cap = cap | lds->xg[nb]; }
+            }
+            const BB nown = own | BB::bit(a), nopp = opp & ~cap;
+            const BB np0 = c.player ? nopp : nown, np1 = c.player ? nown : nopp;
+            bool repeat = false;
+            for (int i = 0; i < n_hist; ++i) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
+            ok = has_libs && !repeat;
+        }
+        const uint64_t m = wv::ballot(ok);
+        legal.w[st] = m;
+    }
+    return legal;
+}
+
+template <class G>
+SPRL_DEV void make_child(GameW& g, WaveLdsW<G>* lds, const PosW<G::WORDS>& parent, int action, int at,
+                         PosW<G::WORDS>& cs) {
+    G::apply(parent, action, cs);
+    if (wv::lane() == 0) {
+        lds->hist[at][0] = cs.p0;
+        lds->hist[at][1] = cs.p1;
+    }
+    wv::sync();
+    if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, at + 1);
+}
+
+// Dirichlet root noise (UCTNode.hpp:330-347, utils/random.cpp:61-74)
+template <class G>
+SPRL_DEV void mix_root_noise(const EngineParams& P, GameW& g, uint8_t* np, const Bits<G::WORDS>& legal, bool pass_legal,
+                             float pass_p) {
+    const int l = wv::lane();
+    NodeHdrW<G::WORDS>* h = hdr_of<G>(np);
+    const int num_legal = legal.popc() + (pass_legal ? 1 : 0);
+    bool mine[WS];
+    int my_rank[WS];
+    float my_noise[WS];
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        mine[st] = a < G::NA && legal.test(a);
+        my_rank[st] = a < G::NA ? legal.rank(a) : 0;
+        my_noise[st] = 0.0f;
+    }
+    NormalState ns = { 0.0f, 0 };
+    float pass_noise = 0.0f, sum = 0.0f;
+    for (int i = 0; i < num_legal; ++i) {
+        float s = rng_gamma(g.rng, ns, P.dir_alpha);
+        sum += s;
+        for (int st = 0; st < WS; ++st)
+            if (mine[st] && my_rank[st] == i) my_noise[st] = s;
+        if (i == num_legal - 1 && pass_legal) pass_noise = s;
+    }
+    const float norm = 1.0f / sum;
+    const double keep = 1.0 - (double)P.dir_eps;
+    for (int st = 0; st < WS; ++st)
+        if (mine[st]) {
+            float p = rowP<G>(np)[st * 64 + l];
+            rowP<G>(np)[st * 64 + l] = (float)(keep * (double)p + (double)(P.dir_eps * (my_noise[st] * norm)));
+        }
+    if (pass_legal) h->passP = (float)(keep * (double)pass_p + (double)(P.dir_eps * (pass_noise * norm)));
+}
+
+template <class G>
+SPRL_DEV void expand_node(const EngineParams& P, GameW& g, uint8_t* np, const NodeHdrW<G::WORDS>& hc, bool add_noise) {
+    const int l = wv::lane();
+    NodeHdrW<G::WORDS>* h = hdr_of<G>(np);
+    const bool pass_legal = (hc.flags & F_PASS) != 0;
+    for (int st = 0; st < WS; ++st) {
+        rowN<G>(np)[st * 64 + l] = 0.0f;
+        rowW<G>(np)[st * 64 + l] = 0.0f;
+    }
+    h->passN = 0.0f;
+    h->passW = 0.0f;
+    h->exp_epoch = g.epoch;
+    if (add_noise) mix_root_noise<G>(P, g, np, hc.legal, pass_legal, hc.passP);
+    g.d_expansions++;
+}
+
+// backup over a stored path: lane j owns edges j, j + 64, ... (UCTTree.hpp:261-273)
+template <class G>
+SPRL_DEV void backup_path(GameW& g, const uint32_t* path, int depth, int leaf_player, float value) {
+    const int l = wv::lane();
+    wv::sync();
+    const float est = -value * (leaf_player == 0 ? 1.0f : -1.0f);
+    g.rootW += 1.0f + est * (g.root_player == 0 ? 1.0f : -1.0f);
+    for (int j = l; j < depth; j += 64) {
+        const uint32_t e = path[j];
+        const uint32_t node = e >> 10;
+        const int a = (int)(e & 0x3ffu);
+        const int child_player = (int)(g.root_player ^ ((uint32_t)(j + 1) & 1u));
+        const float add = 1.0f + est * (child_player == 0 ? 1.0f : -1.0f);
+        uint8_t* np = node_at<G>(g.abase, node);
+        float* wp = a == WPASS ? &hdr_of<G>(np)->passW : &rowW<G>(np)[a];
+        *wp = *wp + add;
+    }
+    wv::wave_fence();
+}
+
+// evaluator output -> cached policy in the P rows (UCTTree.hpp:136-175, GridNetwork.hpp:104-138, RandomNetwork.hpp)
+template <class G>
+SPRL_DEV void evaluate_leaf(const EngineParams& P, GameW& g, WaveLdsW<G>* lds, uint8_t* np, NodeHdrW<G::WORDS>& hc,
+                            int sym, const float* logits, float nn_value) {
+    using BB = Bits<G::WORDS>;
+    const int l = wv::lane();
+    NodeHdrW<G::WORDS>* h = hdr_of<G>(np);
+    const BB legal = hc.legal;
+    const bool pass_legal = (hc.flags & F_PASS) != 0;
+    BB used = legal;
+    if (P.mask_frame == MASK_SYMMETRISED && sym != 0) {
+        for (int st = 0; st < WS; ++st) {
+            const int a = st * 64 + l;
+            const int src = a < G::NA ? G::map_action(G::inverse_sym(sym), a) : 0;
+            used.w[st] = wv::ballot(a < G::NA && legal.test(src));
+        }
+    }
+    const int num_legal = used.popc() + (pass_legal ? 1 : 0);
+    float pol[WS], pass_pol = 0.0f, value = 0.0f;
+    if (P.eval_kind == EVAL_NETWORK) {
+        float e[WS];
+        for (int st = 0; st < WS; ++st) {
+            const int a = st * 64 + l;
+            e[st] = (a < G::NA && used.test(a)) ? sprl_expf(logits[a]) : 0.0f;
+        }
+        const float e_pass = pass_legal ? sprl_expf(logits[G::A - 1]) : 0.0f;
+        float sum = 0.0f;
+        for (int st = 0; st < WS; ++st)
+            for (uint64_t m = used.w[st]; m; m &= m - 1) sum += wv::bcast_f32(e[st], wv::ctz64(m));
+        if (pass_legal) sum += e_pass;
+        if (sum == 0.0f) {
+            const float uniform = 1.0f / (float)num_legal;
+            for (int st = 0; st < WS; ++st) pol[st] = (st * 64 + l < G::NA && used.test(st * 64 + l)) ? uniform : 0.0f;
+            pass_pol = pass_legal ? uniform : 0.0f;
+        } else {
+            const float inv = 1.0f / sum;
+            for (int st = 0; st < WS; ++st) pol[st] = e[st] * inv;
+            pass_pol = e_pass * inv;
+        }
+        value = nn_value;
+    } else {
+        const float uniform = 1.0f / (float)num_legal;
+        for (int st = 0; st < WS; ++st) pol[st] = (st * 64 + l < G::NA && used.test(st * 64 + l)) ? uniform : 0.0f;
+        pass_pol = pass_legal ? uniform : 0.0f;
+    }
+    // undo the symmetry through LDS: policy_orig[a] = policy_sym[map_s(a)]
+    wv::sync();
+    for (int st = 0; st < WS; ++st) lds->xf[st * 64 + l] = pol[st];
+    wv::sync();
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        const bool legal_here = a < G::NA && legal.test(a);
+        const float v = a < G::NA ? lds->xf[G::map_action(sym, a)] : 0.0f;
+        rowP<G>(np)[a] = legal_here ? v : 0.0f;
+    }
+    hc.passP = pass_legal ? pass_pol : 0.0f;
+    hc.value = value;
+    hc.flags = (uint8_t)(hc.flags | F_EVAL);
+    h->passP = hc.passP;
+    h->value = hc.value;
+    h->flags = hc.flags;
+}
+
+template <class G>
+SPRL_DEV void encode_leaf(const EngineParams& P, const WaveLdsW<G>* lds, int q, int player, int sym, int nn_slot) {
+    const int l = wv::lane();
+    float* out = P.nn_in + (size_t)nn_slot * (G::PLANES * G::CELLS);
+    const int size = (int)lds->leaf_size[q];
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        if (a >= G::CELLS) continue;
+        const int src = G::map_cell(G::inverse_sym(sym), a);
+        for (int t = 0; t < G::HIST; ++t) {
+            const Bits<G::WORDS>& p0 = lds->leaf_hist[q][t][0];
+            const Bits<G::WORDS>& p1 = lds->leaf_hist[q][t][1];
+            const bool own = player ? p1.test(src) : p0.test(src), opp = player ? p0.test(src) : p1.test(src);
+            out[(2 * t) * G::CELLS + a] = (t < size && own) ? 1.0f : 0.0f;
+            out[(2 * t + 1) * G::CELLS + a] = (t < size && opp) ? 1.0f : 0.0f;
+        }
+        out[(2 * G::HIST) * G::CELLS + a] = player == 0 ? 1.0f : 0.0f;
+    }
+}
+
+template <class G>
+SPRL_DEV void finish_leaves(const EngineParams& P, GameW& g, int slot, GameCtl* ctl, WaveLdsW<G>* lds) {
+    const int nn_base = (int)P.leaf_offset[slot];
+    for (int q = 0; q < g.n_leaves; ++q) {
+        const uint32_t leaf = ctl->leaf_node[q];
+        const int depth = (int)ctl->leaf_depth[q];
+        const int sym = (int)ctl->leaf_sym[q];
+        uint8_t* np = node_at<G>(g.abase, leaf);
+        NodeHdrW<G::WORDS> h = load_hdr<G>(np);
+        const float* logits = P.nn_logits + (size_t)(nn_base + q) * G::A;
+        const float nn_value = P.eval_kind == EVAL_NETWORK ? P.nn_value[nn_base + q] : 0.0f;
+        if (!(h.flags & F_EVAL)) evaluate_leaf<G>(P, g, lds, np, h, sym, logits, nn_value);
+        else g.d_dup++;
+        if (h.exp_epoch != g.epoch) expand_node<G>(P, g, np, h, P.add_noise && leaf == g.root);
+        const uint32_t* path = P.paths + ((size_t)slot * SPRL_MAXQ + q) * P.max_depth;
+        backup_path<G>(g, path, depth, h.player, h.value);
+    }
+    g.n_leaves = 0;
+}
+
+template <class G>
+SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* ctl, WaveLdsW<G>* lds) {
+    using BB = Bits<G::WORDS>;
+    const int l = wv::lane();
+    int trav = 0;
+    while (trav < P.max_batch) {
+        ++trav;
+        uint32_t cur = g.root;
+        float nself = g.rootN;
+        g.rootN += 1.0f;
+        g.rootW -= 1.0f;
+        int depth = 0;
+        NodeHdrW<G::WORDS> h = load_hdr<G>(node_at<G>(g.abase, cur));
+        if (l == 0) {
+            lds->hist[g.ply][0] = h.p0;
+            lds->hist[g.ply][1] = h.p1;
+        }
+        while (h.exp_epoch == g.epoch && !(h.flags & F_TERMINAL)) {
+            uint8_t* np = node_at<G>(g.abase, cur);
+            float n[WS], w[WS], score[WS];
+            uint32_t ch[WS];
+            bool lg[WS];
+            const float sq = __builtin_sqrtf(nself);
+            float local = -__builtin_inff();
+            for (int st = 0; st < WS; ++st) {
+                const int a = st * 64 + l;
+                n[st] = rowN<G>(np)[a];
+                w[st] = rowW<G>(np)[a];
+                const float p = rowP<G>(np)[a];
+                ch[st] = rowC<G>(np)[a];
+                lg[st] = a < G::NA && h.legal.test(a);
+                const float den = 1.0f + n[st];
+                score[st] = w[st] / den + P.u_weight * (p * sq / den);       // UCTNode.hpp:200,210,236
+                if (lg[st] && score[st] > local) local = score[st];
+            }
+            wv::sync();
+            const float pden = 1.0f + h.passN;
+            const float pscore = h.passW / pden + P.u_weight * (h.passP * sq / pden);
+            float best = wv::fmax_all(local);
+            best = pscore > best ? pscore : best;
+            uint64_t ties[WS];
+            int kb = 0;
+            for (int st = 0; st < WS; ++st) {
+                ties[st] = wv::ballot(lg[st] && score[st] == best);
+                kb += wv::popc64(ties[st]);
+            }
+            const int k = kb + (pscore == best ? 1 : 0);
+            int r = rng_uniform_int(g.rng, (uint32_t)k);                     // UCTNode.hpp:250
+            int a = WPASS;
+            if (r < kb) {
+                for (int st = 0; st < WS; ++st) {
+                    const int c = wv::popc64(ties[st]);
+                    if (r < c) { a = st * 64 + wv::nth_set_bit(ties[st], r); break; }
+                    r -= c;
+                }
+            }
+            g.d_levels++;
+            if (depth >= P.max_depth) { raise_error(P, g, ERR_MAX_DEPTH); return; }
+            if (l == 0) lds->path[depth] = (cur << 10) | (uint32_t)a;
+            ++depth;
+            NodeHdrW<G::WORDS>* hp = hdr_of<G>(np);
+            uint32_t c = SPRL_NONE16;
+            float n_a = 0.0f, w_a = 0.0f;
+            if (a == WPASS) {
+                c = h.passChild;
+                n_a = h.passN;
+                w_a = h.passW;
+            } else {
+                const int sa = a >> 6, la = a & 63;
+                for (int st = 0; st < WS; ++st)
+                    if (st == sa) {
+                        c = wv::bcast_u32(ch[st], la);
+                        n_a = wv::bcast_f32(n[st], la);
+                        w_a = wv::bcast_f32(w[st], la);
+                    }
+            }
+            bool created = false;
+            PosW<G::WORDS> cs;
+            if (c == SPRL_NONE16) {
+                c = g.n_alloc++;
+                created = true;
+                make_child<G>(g, lds, pos_of<G>(h), a, g.ply + depth, cs);
+                write_new_node<G>(node_at<G>(g.abase, c), cs, a);
+                w_a = h.value;                                               // InitQ::PARENT
+                g.d_created++;
+                if (a == WPASS) hp->passChild = c;
+                else if ((a & 63) == l) rowC<G>(np)[a] = (uint16_t)c;
+            }
+            if (a == WPASS) {
+                hp->passN = n_a + 1.0f;
+                hp->passW = w_a - 1.0f;
+            } else if ((a & 63) == l) {
+                rowN<G>(np)[a] = n_a + 1.0f;
+                rowW<G>(np)[a] = w_a - 1.0f;
+            }
+            nself = n_a;
+            cur = c;
+            if (created) {
+                h.p0 = cs.p0; h.p1 = cs.p1; h.legal = cs.legal; h.value = 0.0f; h.exp_epoch = 0;
+                h.passChild = SPRL_NONE16; h.player = cs.player; h.winner = cs.winner;
+                h.flags = (uint8_t)((cs.terminal ? F_TERMINAL : 0) | (cs.pass_legal ? F_PASS : 0));
+                h.action = (uint16_t)a; h.depth = cs.depth;
+                break;
+            }
+            h = load_hdr<G>(node_at<G>(g.abase, cur));
+            if (l == 0) {
+                lds->hist[g.ply + depth][0] = h.p0;
+                lds->hist[g.ply + depth][1] = h.p1;
+            }
+        }
+        if (h.flags & F_TERMINAL) {
+            const float value = h.winner < 0 ? 0.0f : (h.winner == (int8_t)h.player ? 1.0f : -1.0f);
+            backup_path<G>(g, lds->path, depth, h.player, value);
+            g.d_terminal++;
+            continue;
+        } else if (h.flags & F_EVAL) {
+            expand_node<G>(P, g, node_at<G>(g.abase, cur), h, P.add_noise && cur == g.root);
+            backup_path<G>(g, lds->path, depth, h.player, h.value);
+            g.d_gray++;
+            continue;
+        } else {
+            const int q = g.n_leaves++;
+            ctl->leaf_node[q] = cur;
+            ctl->leaf_depth[q] = (uint32_t)depth;
+            ctl->leaf_player[q] = h.player;
+            uint32_t* path = P.paths + ((size_t)slot * SPRL_MAXQ + q) * P.max_depth;
+            wv::sync();
+            for (int j = l; j < depth; j += 64) path[j] = lds->path[j];
+            const int last = g.ply + depth;
+            const int size = last + 1 < G::HIST ? last + 1 : G::HIST;
+            if (l < size) {
+                lds->leaf_hist[q][l][0] = lds->hist[last - l][0];
+                lds->leaf_hist[q][l][1] = lds->hist[last - l][1];
+            }
+            if (l == 0) lds->leaf_size[q] = (uint32_t)size;
+        }
+        if (g.n_leaves >= P.max_queue) break;
+    }
+    g.traversals += trav;
+    g.d_traversals += (uint32_t)trav;
+    for (int q = 0; q < g.n_leaves; ++q) {
+        int sym = 0;
+        if (P.use_sym) sym = rng_uniform_int(g.rng, (uint32_t)G::NSYM);
+        ctl->leaf_sym[q] = (uint32_t)sym;
+        if (P.eval_kind == EVAL_NETWORK) {
+            wv::sync();
+            encode_leaf<G>(P, lds, q, (int)ctl->leaf_player[q], sym, slot * P.max_queue + q);
+        }
+    }
+    g.d_nn_evals += (uint32_t)g.n_leaves;
+}
+
+// arena compaction: Cheney copy of the live subtree into a spare arena (same protocol as step_kernel.h)
+template <class G>
+SPRL_DEV void copy_node(const uint8_t* src, uint8_t* dst) {
+    struct alignas(16) Chunk { uint32_t x[4]; };
+    for (int i = wv::lane(); i < G::NODE_BYTES / 16; i += 64) ((Chunk*)dst)[i] = ((const Chunk*)src)[i];
+}
+
+template <class G>
+SPRL_DEV bool compact_arena(const EngineParams& P, GameW& g) {
+    const int l = wv::lane();
+    uint32_t got = 0xFFFFFFFFu;
+    if (l == 0) {
+        const uint32_t total = (uint32_t)(P.num_slots + P.num_spare);
+        for (uint32_t i = 0; i < total; ++i) {
+            uint32_t idx = (g.arena + 1 + i) % total;
+            if (wv::atomic_cas_u32(&P.arena_used[idx], 0u, 1u) == 0u) { got = idx; break; }
+        }
+    }
+    got = wv::bcast_u32(got, 0);
+    if (got == 0xFFFFFFFFu) { raise_error(P, g, ERR_NO_SPARE); return false; }
+    wv::agent_acquire();
+    uint8_t* from = g.abase;
+    uint8_t* to = P.arenas + (size_t)got * (size_t)P.node_cap * G::NODE_BYTES;
+    copy_node<G>(node_at<G>(from, g.root), node_at<G>(to, 0));
+    wv::wave_fence();
+    uint32_t scan = 0, free_ = 1;
+    while (scan < free_) {
+        uint8_t* np = node_at<G>(to, scan);
+        for (int st = 0; st < WS; ++st) {
+            uint32_t ch = rowC<G>(np)[st * 64 + l];
+            const bool has = ch != SPRL_NONE16;
+            const uint64_t mask = wv::ballot(has);
+            if (has) rowC<G>(np)[st * 64 + l] = (uint16_t)(free_ + (uint32_t)wv::popc64(mask & wv::lt_mask(l)));
+            uint32_t k = 0;
+            for (uint64_t m = mask; m; m &= m - 1, ++k) {
+                uint32_t src = wv::bcast_u32(ch, wv::ctz64(m));
+                copy_node<G>(node_at<G>(from, src), node_at<G>(to, free_ + k));
+            }
+            free_ += k;
+        }
+        NodeHdrW<G::WORDS>* h = hdr_of<G>(np);
+        const uint32_t pc = h->passChild;
+        wv::sync();
+        if (pc != SPRL_NONE16) {
+            copy_node<G>(node_at<G>(from, pc), node_at<G>(to, free_));
+            h->passChild = free_;
+            ++free_;
+        }
+        wv::wave_fence();
+        ++scan;
+    }
+    wv::agent_release();
+    if (l == 0) wv::atomic_store_u32(&P.arena_used[g.arena], 0u);
+    g.arena = got;
+    g.abase = to;
+    g.root = 0;
+    g.n_alloc = free_;
+    g.d_compactions++;
+    return true;
+}
+
+template <class G>
+SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds) {
+    uint32_t gid = 0;
+    if (wv::lane() == 0) gid = wv::atomic_add_u32(&P.counters->next_game, 1u);
+    gid = wv::bcast_u32(gid, 0);
+    if (gid >= (uint32_t)P.num_games) {
+        g.status = ST_IDLE;
+        return;
+    }
+    g.status = ST_ACTIVE;
+    g.game_id = gid;
+    rng_seed(g.rng, P.seed, P.stream_base + (int)gid);
+    PosW<G::WORDS> s;
+    G::start(s);
+    write_new_node<G>(node_at<G>(g.abase, 0), s, 0);
+    g.root = 0;
+    g.n_alloc = 1;
+    g.epoch = 1;
+    g.root_player = 0;
+    g.rootN = 0.0f;
+    g.rootW = 0.0f;
+    g.ply = 0;
+    g.traversals = 0;
+    g.n_leaves = 0;
+    g.d_created++;
+    if (wv::lane() == 0) {
+        lds->hist[0][0] = s.p0;
+        lds->hist[0][1] = s.p1;
+    }
+    Bits<G::WORDS>* gh = (Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
+    gh[0] = s.p0;
+    gh[1] = s.p1;
+}
+
+// SelfPlay.hpp:110-148
+template <class G>
+SPRL_DEV void play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds) {
+    const int l = wv::lane();
+    uint8_t* np = node_at<G>(g.abase, g.root);
+    const NodeHdrW<G::WORDS> h = load_hdr<G>(np);
+    float visits[WS], pdf[WS], cdf[WS];
+    uint64_t nz[WS];
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        visits[st] = a < G::NA ? rowN<G>(np)[a] : 0.0f;
+    }
+    wv::sync();
+    const float pass_visits = h.passN;
+    float sum = 0.0f;
+    for (int st = 0; st < WS; ++st) {
+        nz[st] = wv::ballot(visits[st] != 0.0f);
+        for (uint64_t m = nz[st]; m; m &= m - 1) sum += wv::bcast_f32(visits[st], wv::ctz64(m));
+    }
+    sum += pass_visits;
+    float inv = 1.0f / sum;
+    const float ex = g.ply < P.early_cutoff ? P.early_exp : P.rest_exp;
+    float pass_pdf = sprl_powf(pass_visits * inv, ex);
+    for (int st = 0; st < WS; ++st) pdf[st] = sprl_powf(visits[st] * inv, ex);
+    sum = 0.0f;
+    for (int st = 0; st < WS; ++st)
+        for (uint64_t m = nz[st]; m; m &= m - 1) sum += wv::bcast_f32(pdf[st], wv::ctz64(m));
+    sum += pass_pdf;
+    inv = 1.0f / sum;
+    for (int st = 0; st < WS; ++st) pdf[st] = pdf[st] * inv;
+    pass_pdf = pass_pdf * inv;
+    float run = 0.0f;
+    for (int st = 0; st < WS; ++st) {
+        cdf[st] = run;                                   // prefix over all earlier strips
+        for (uint64_t m = nz[st]; m; m &= m - 1) {
+            const int k = wv::ctz64(m);
+            run += wv::bcast_f32(pdf[st], k);
+            if (l >= k) cdf[st] = run;
+        }
+    }
+    float last = run + pass_pdf;
+    inv = 1.0f / last;
+    for (int st = 0; st < WS; ++st) cdf[st] = cdf[st] * inv;
+    last = last * inv;
+    if (g.ply >= P.max_plies) { raise_error(P, g, ERR_MAX_PLIES); return; }
+    const size_t rec = (size_t)g.game_id * (size_t)P.max_plies + (size_t)g.ply;
+    Bits<G::WORDS>* rb = (Bits<G::WORDS>*)P.rec_boards + rec * 2;
+    rb[0] = h.p0;
+    rb[1] = h.p1;
+    P.rec_movers[rec] = h.player;
+    for (int st = 0; st < WS; ++st)
+        if (st * 64 + l < G::NA) P.rec_pdf[rec * G::A + st * 64 + l] = pdf[st];
+    P.rec_pdf[rec * G::A + (G::A - 1)] = pass_pdf;
+    float e;
+    do {
+        e = rng_uniform_float(g.rng);
+    } while (e == 0.0f);
+    const float x = last * e;
+    int action = WPASS;
+    for (int st = 0; st < WS; ++st) {
+        const uint64_t ge = wv::ballot(st * 64 + l < G::NA && !(cdf[st] < x));
+        if (action == WPASS && ge) action = st * 64 + wv::ctz64(ge);
+    }
+    uint32_t c = SPRL_NONE16;
+    float n_a = 0.0f, w_a = 0.0f;
+    if (action == WPASS) {
+        c = h.passChild;
+        n_a = h.passN;
+        w_a = h.passW;
+    } else {
+        const int sa = action >> 6, la = action & 63;
+        for (int st = 0; st < WS; ++st) {
+            const uint32_t cc = wv::bcast_u32((uint32_t)rowC<G>(np)[st * 64 + l], la);
+            const float nn = wv::bcast_f32(visits[st], la);
+            const float ww = wv::bcast_f32(rowW<G>(np)[st * 64 + l], la);
+            if (st == sa) { c = cc; n_a = nn; w_a = ww; }
+        }
+    }
+    if (c == SPRL_NONE16) {
+        PosW<G::WORDS> cs;
+        make_child<G>(g, lds, pos_of<G>(h), action, g.ply + 1, cs);
+        c = g.n_alloc++;
+        write_new_node<G>(node_at<G>(g.abase, c), cs, action);
+        w_a = (h.flags & F_EVAL) ? h.value : 0.0f;
+    }
+    g.root = c;
+    g.rootN = n_a;
+    g.rootW = w_a;
+    g.root_player ^= 1u;
+    g.ply += 1;
+    {
+        const NodeHdrW<G::WORDS> nh = load_hdr<G>(node_at<G>(g.abase, c));
+        if (l == 0) {
+            lds->hist[g.ply][0] = nh.p0;
+            lds->hist[g.ply][1] = nh.p1;
+        }
+        Bits<G::WORDS>* gh = (Bits<G::WORDS>*)P.hist_boards + ((size_t)slot * G::HIST_CAP + (size_t)g.ply) * 2;
+        gh[0] = nh.p0;
+        gh[1] = nh.p1;
+    }
+    g.epoch += 1;
+    g.traversals = 0;
+    g.d_plies++;
+}
+
+template <class G>
+SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
+    GameCtl* ctl = P.ctl + slot;
+    GameW g;
+    g.status = ctl->status;
+    if (g.status == ST_IDLE || g.status == ST_ERROR) return;
+    g.rng.state = ctl->rng_state;
+    g.rng.inc = ctl->rng_inc;
+    g.game_id = ctl->game_id;
+    g.arena = ctl->arena;
+    g.root = ctl->root;
+    g.n_alloc = ctl->n_alloc;
+    g.epoch = ctl->epoch;
+    g.rootN = ctl->rootN;
+    g.rootW = ctl->rootW;
+    g.ply = ctl->ply;
+    g.traversals = ctl->traversals;
+    g.n_leaves = ctl->n_leaves;
+    g.root_player = ctl->root_player;
+    g.d_traversals = g.d_levels = g.d_expansions = g.d_nn_evals = g.d_terminal = g.d_gray = g.d_dup = 0;
+    g.d_created = g.d_compactions = g.d_games = g.d_plies = 0;
+    g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * G::NODE_BYTES;
+    wv::sync();
+    if (g.status == ST_ACTIVE) {
+        const Bits<G::WORDS>* gh = (const Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
+        for (int i = wv::lane(); i <= g.ply; i += 64) {
+            lds->hist[i][0] = gh[2 * i];
+            lds->hist[i][1] = gh[2 * i + 1];
+        }
+        wv::sync();
+    }
+    if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);
+
+    int round = 0;
+    while (g.status == ST_ACTIVE) {
+        if (g.n_leaves > 0) {
+            if (P.eval_kind == EVAL_NETWORK && round > 0) break;
+            finish_leaves<G>(P, g, slot, ctl, lds);
+        }
+        bool idle = false;
+        while (g.traversals >= P.num_traversals) {
+            play_move<G>(P, g, slot, lds);
+            if (g.status != ST_ACTIVE) break;
+            const NodeHdrW<G::WORDS> rh = load_hdr<G>(node_at<G>(g.abase, g.root));
+            if (rh.flags & F_TERMINAL) {
+                P.rec_nplies[g.game_id] = g.ply;
+                P.rec_winner[g.game_id] = rh.winner;
+                g.d_games++;
+                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
+                start_game<G>(P, g, slot, lds);
+                if (g.status != ST_ACTIVE) { idle = true; break; }
+            }
+        }
+        if (idle || g.status != ST_ACTIVE) break;
+        if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) {
+            if (!compact_arena<G>(P, g)) break;
+            if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
+        }
+        select_batch<G>(P, g, slot, ctl, lds);
+        ++round;
+        if (P.eval_kind != EVAL_NETWORK && round >= P.rounds) break;
+    }
+
+    ctl->status = g.status;
+    ctl->rng_state = g.rng.state;
+    ctl->rng_inc = g.rng.inc;
+    ctl->game_id = g.game_id;
+    ctl->arena = g.arena;
+    ctl->root = g.root;
+    ctl->n_alloc = g.n_alloc;
+    ctl->epoch = g.epoch;
+    ctl->rootN = g.rootN;
+    ctl->rootW = g.rootW;
+    ctl->ply = g.ply;
+    ctl->traversals = g.traversals;
+    ctl->n_leaves = g.n_leaves;
+    ctl->root_player = g.root_player;
+    if (wv::lane() == 0) {
+        GameStats& t = ctl->stats;
+        t.traversals += g.d_traversals;
+        t.levels += g.d_levels;
+        t.expansions += g.d_expansions;
+        t.nn_evals += g.d_nn_evals;
+        t.terminal_hits += g.d_terminal;
+        t.gray_hits += g.d_gray;
+        t.dup_hits += g.d_dup;
+        t.nodes_created += g.d_created;
+        t.compactions += g.d_compactions;
+        t.games += g.d_games;
+        t.plies += g.d_plies;
+        if (g.n_alloc > t.max_alloc) t.max_alloc = g.n_alloc;
+    }
+    P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
+    if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
+}
+
+}  // namespace sprlw
+
+#endif  // SPRL_STEP_KERNEL_WIDE_H
