@@ -26,6 +26,8 @@ static geom_t geom(int game) {
         g.rows = 6; g.cols = 7; g.cells = 42; g.A = 7; g.nsym = 2; g.hist = 1;
     } else if (game == ORC_GAME_GO7) {   /* games/GoNode.hpp:16-22: 7x7, 8-ply history, 49 + pass */
         g.rows = 7; g.cols = 7; g.cells = 49; g.A = 50; g.nsym = 8; g.hist = 8;
+    } else if (game == ORC_GAME_GO9) {   /* the same rules at width 9 (BASELINE config 4; not reference-pinned) */
+        g.rows = 9; g.cols = 9; g.cells = 81; g.A = 82; g.nsym = 8; g.hist = 8;
     } else {                             /* games/OthelloNode.hpp:8-11 */
         g.rows = 8; g.cols = 8; g.cells = 64; g.A = 65; g.nsym = 8; g.hist = 1;
     }
@@ -293,33 +295,37 @@ static void c4_step(const int8_t* board, int player, const float* mask, int acti
 /* ------------------------------------------------------------------------------------------ */
 /* Go 7x7 — games/GoNode.{hpp,cpp}, utils/DSU.hpp, utils/Zobrist.hpp                            */
 /* ------------------------------------------------------------------------------------------ */
-#define GO_W 7
-#define GO_N 49
-#define GO_PASS 49
+/* The reference fixes the board at 7x7 (GoNode.hpp:16); 9x9 is the same code with the width as a parameter
+ * (komi 7.5 there, games/GoDesc.md:127-128).  Only the 7x7 instance is pinned against the reference build. */
+#define GO_NMAX 81
+#define GO_W (s->w)
+#define GO_N (s->w * s->w)
+#define GO_PASS GO_N
 #define GO_MAX_DEPTH (2 * GO_N)                  /* GoNode.hpp:22 */
-#define GO_KOMI 9.0f                             /* GoNode.hpp:20 */
+#define GO_KOMI (s->w == 7 ? 9.0f : 7.5f)        /* GoNode.hpp:20 */
 
 typedef struct {
-    int8_t board[GO_N];
-    int8_t dsu[GO_N];                            /* utils/DSU.hpp (path compression omitted: same sets) */
-    int8_t libs[GO_N];                           /* valid at group roots */
-    uint64_t comp[GO_N];                         /* per-group Zobrist value, valid at group roots */
+    int w;                                       /* board width */
+    int8_t board[GO_NMAX];
+    int8_t dsu[GO_NMAX];                         /* utils/DSU.hpp (path compression omitted: same sets) */
+    int8_t libs[GO_NMAX];                        /* valid at group roots */
+    uint64_t comp[GO_NMAX];                      /* per-group Zobrist value, valid at group roots */
     uint64_t hash;
     int depth;
     int action;                                  /* action that led here (m_action), 0 at the start node */
-    uint64_t hist[GO_MAX_DEPTH + 2];             /* m_zobristHistorySet: hashes after every placement */
+    uint64_t hist[2 * GO_NMAX + 2];              /* m_zobristHistorySet: hashes after every placement */
     int nhist;
 } go_state;
 
 /* The reference draws its Zobrist table from the process-global RNG at static-init time (Zobrist.hpp:42-47),
  * i.e. it is random per process and only matters through collisions; any fixed table is equivalent. */
 static uint64_t go_zobrist(int coord, int piece) {
-    uint64_t z = 0x9E3779B97F4A7C15ULL * (uint64_t)(coord + piece * GO_N + 1);
+    uint64_t z = 0x9E3779B97F4A7C15ULL * (uint64_t)(coord + piece * GO_NMAX + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-static int go_neighbors(int c, int* out) {                                   /* GoNode.hpp:117-130 */
+static int go_neighbors(const go_state* s, int c, int* out) {                                   /* GoNode.hpp:117-130 */
     int n = 0, row = c / GO_W, col = c % GO_W;
     if (row > 0) out[n++] = c - GO_W;
     if (col > 0) out[n++] = c - 1;
@@ -339,12 +345,12 @@ static int go_has_hash(const go_state* s, uint64_t h) {
 static int go_compute_liberties(const go_state* s, int coord) {              /* GoNode.cpp:10-52 */
     int piece = s->board[coord];
     if (piece == -1) return 0;
-    int visited[GO_N] = { 0 }, q[GO_N], qh = 0, qt = 0, libs = 0, nb[4];
+    int visited[GO_NMAX] = { 0 }, q[GO_NMAX], qh = 0, qt = 0, libs = 0, nb[4];
     visited[coord] = 1;
     q[qt++] = coord;
     while (qh < qt) {
         int cur = q[qh++];
-        int k = go_neighbors(cur, nb);
+        int k = go_neighbors(s, cur, nb);
         for (int i = 0; i < k; ++i) {
             int n = nb[i];
             if (s->board[n] == piece) {
@@ -362,7 +368,7 @@ static void go_clear_component(go_state* s, int coord, int piece) {          /* 
     s->libs[go_find(s, coord)] = 0;
     s->comp[go_find(s, coord)] = 0;
     int groups[4], ng = 0, nb[4];
-    int k = go_neighbors(coord, nb);
+    int k = go_neighbors(s, coord, nb);
     for (int i = 0; i < k; ++i) {
         int n = nb[i];
         if (s->board[n] == -1) continue;
@@ -382,7 +388,7 @@ static void go_place(go_state* s, int coord, int piece) {                    /* 
     int nb[4];
     s->board[coord] = (int8_t)piece;
     uint64_t new_comp = go_zobrist(coord, piece);
-    int k = go_neighbors(coord, nb);
+    int k = go_neighbors(s, coord, nb);
     for (int i = 0; i < k; ++i) {
         int n = nb[i];
         if (s->board[n] == piece) {
@@ -418,7 +424,7 @@ static int go_legal(const go_state* s, int coord, int piece) {               /* 
     if (s->board[coord] != -1) return 0;
     uint64_t nh = s->hash ^ go_zobrist(coord, piece);
     int has_libs = 0, groups[4], ng = 0, nb[4];
-    int k = go_neighbors(coord, nb);
+    int k = go_neighbors(s, coord, nb);
     for (int i = 0; i < k; ++i) {
         int n = nb[i];
         if (s->board[n] == -1) {
@@ -440,19 +446,19 @@ static int go_legal(const go_state* s, int coord, int piece) {               /* 
     return has_libs && !go_has_hash(s, nh);
 }
 static void go_territory(const go_state* s, int* terr) {                     /* GoNode.cpp:230-290 */
-    int visited[GO_N] = { 0 }, nb[4];
+    int visited[GO_NMAX] = { 0 }, nb[4];
     terr[0] = terr[1] = 0;
     for (int i = 0; i < GO_N; ++i) {
         if (s->board[i] == 0) { terr[0]++; continue; }
         if (s->board[i] == 1) { terr[1]++; continue; }
         if (visited[i]) continue;
-        int q[GO_N], qh = 0, qt = 0, count = 0, poss0 = 1, poss1 = 1;
+        int q[GO_NMAX], qh = 0, qt = 0, count = 0, poss0 = 1, poss1 = 1;
         visited[i] = 1;
         q[qt++] = i;
         while (qh < qt) {
             int cur = q[qh++];
             ++count;
-            int k = go_neighbors(cur, nb);
+            int k = go_neighbors(s, cur, nb);
             for (int j = 0; j < k; ++j) {
                 int n = nb[j];
                 if (s->board[n] == 0) poss1 = 0;
@@ -464,20 +470,22 @@ static void go_territory(const go_state* s, int* terr) {                     /* 
         if (poss1 && !poss0) terr[1] += count;
     }
 }
-static void go_start(go_state* s) {                                          /* GoNode.cpp:303-317 */
+static void go_start(go_state* s, int width) {                               /* GoNode.cpp:303-317 */
     memset(s, 0, sizeof(*s));
-    memset(s->board, -1, GO_N);
-    for (int i = 0; i < GO_N; ++i) s->dsu[i] = (int8_t)i;
+    s->w = width;
+    memset(s->board, -1, GO_NMAX);
+    for (int i = 0; i < GO_NMAX; ++i) s->dsu[i] = (int8_t)i;
 }
 static void go_next(const go_state* p, int player, int action, go_state* c, float* mask, int* terminal,
                     int* winner) {                                           /* GoNode.cpp:319-383 */
+    const go_state* s = p;
     *c = *p;
     if (action != GO_PASS) go_place(c, action, player);
     c->action = action;
     c->depth = p->depth + 1;
     *terminal = (p->action == GO_PASS && action == GO_PASS) || c->depth >= GO_MAX_DEPTH;
     *winner = -1;
-    for (int a = 0; a < 50; ++a) mask[a] = 0.0f;
+    for (int a = 0; a <= GO_N; ++a) mask[a] = 0.0f;
     if (!*terminal) {
         for (int i = 0; i < GO_N; ++i) mask[i] = (float)go_legal(c, i, 1 - player);
         mask[GO_PASS] = 1.0f;                                                /* :298 */
@@ -497,8 +505,8 @@ void orc_start(int game, int8_t* board, int* player, float* mask) {
     *player = 0;
     if (game == ORC_GAME_C4) {                                               /* ConnectFourNode.cpp:13-21 */
         for (int a = 0; a < 7; ++a) mask[a] = 1.0f;
-    } else if (game == ORC_GAME_GO7) {                                       /* GoNode.cpp:306 */
-        for (int a = 0; a < 50; ++a) mask[a] = 1.0f;
+    } else if (game == ORC_GAME_GO7 || game == ORC_GAME_GO9) {               /* GoNode.cpp:306 */
+        for (int a = 0; a < g.A; ++a) mask[a] = 1.0f;
     } else {                                                                 /* OthelloNode.cpp:18-32 */
         board[3 * 8 + 3] = 1;
         board[3 * 8 + 4] = 0;
@@ -530,9 +538,9 @@ int orc_playout(int game, uint64_t seed, int stream, int max_plies, int8_t* boar
     int player, term = 0, winner = -1, ply = 0;
     go_state* gs = NULL;
     orc_start(game, b, &player, m);
-    if (game == ORC_GAME_GO7) {
+    if (game == ORC_GAME_GO7 || game == ORC_GAME_GO9) {
         gs = (go_state*)malloc(sizeof(go_state) * (size_t)(max_plies + 1));
-        go_start(&gs[0]);
+        go_start(&gs[0], g.cols);
     }
     const size_t stride = (size_t)g.hist * g.cells;
     for (;;) {
@@ -556,7 +564,7 @@ int orc_playout(int game, uint64_t seed, int stream, int max_plies, int8_t* boar
         actions[ply] = (int16_t)a;
         if (gs) {
             go_next(&gs[ply], player, a, &gs[ply + 1], nm, &term, &winner);
-            memcpy(nb, gs[ply + 1].board, GO_N);
+            memcpy(nb, gs[ply + 1].board, (size_t)g.cells);
         } else {
             orc_step(game, b, player, m, a, nb, nm, &term, &winner);
         }
@@ -737,10 +745,10 @@ static node* node_new(tree* t, node* parent, int action) {
     n->parent = parent;
     n->action = action;
     if (parent) {
-        if (t->cfg->game == ORC_GAME_GO7) {
+        if (parent->go) {
             n->go = (go_state*)malloc(sizeof(go_state));
             go_next(parent->go, parent->player, action, n->go, n->mask, &n->terminal, &n->winner);
-            memcpy(n->board, n->go->board, GO_N);
+            memcpy(n->board, n->go->board, (size_t)t->g.cells);
         } else {
             orc_step(t->cfg->game, parent->board, parent->player, parent->mask, action, n->board, n->mask,
                      &n->terminal, &n->winner);
@@ -750,9 +758,9 @@ static node* node_new(tree* t, node* parent, int action) {
         n->own_W = &parent->W[action];
     } else {
         orc_start(t->cfg->game, n->board, &n->player, n->mask);
-        if (t->cfg->game == ORC_GAME_GO7) {
+        if (t->cfg->game == ORC_GAME_GO7 || t->cfg->game == ORC_GAME_GO9) {
             n->go = (go_state*)malloc(sizeof(go_state));
-            go_start(n->go);
+            go_start(n->go, t->g.cols);
         }
         n->winner = -1;
         n->own_N = &t->dummy_N[0];

@@ -5,6 +5,7 @@
 
 #include "backend.h"
 #include "step_kernel.h"
+#include "step_kernel_wide.h"
 
 namespace {
 
@@ -24,6 +25,13 @@ __global__ void __launch_bounds__(64) step_kernel(EngineParams P) {
     __shared__ sprl::WaveLds<G> lds;
     const int slot = (int)blockIdx.x;
     if (slot < P.num_slots) sprl::step_game<G>(P, slot, &lds);
+}
+
+template <class G>
+__global__ void __launch_bounds__(64) step_kernel_wide(EngineParams P) {
+    __shared__ sprlw::WaveLdsW<G> lds;
+    const int slot = (int)blockIdx.x;
+    if (slot < P.num_slots) sprlw::step_game<G>(P, slot, &lds);
 }
 
 // Exclusive scan of the per-slot leaf counts (slot order => the dense batch order is deterministic).
@@ -125,6 +133,8 @@ int launch_step(int game, const EngineParams& P) {
     dim3 grid((unsigned)P.num_slots), block(64);
     if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(step_kernel<Othello>, grid, block, 0, 0, P);
     else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(step_kernel<Go7>, grid, block, 0, 0, P);
+    else if (game == SPRL_GAME_GO9) hipLaunchKernelGGL(step_kernel_wide<GoN<9>>, grid, block, 0, 0, P);
+    else if (game == SPRL_GAME_GO7W) hipLaunchKernelGGL(step_kernel_wide<GoN<7>>, grid, block, 0, 0, P);
     else hipLaunchKernelGGL(step_kernel<ConnectFour>, grid, block, 0, 0, P);
     return ok(hipGetLastError(), "step_kernel launch") ? 0 : -1;
 }

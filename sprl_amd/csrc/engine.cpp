@@ -19,6 +19,7 @@
 #include "backend.h"
 #include "engine_types.h"
 #include "games.h"
+#include "games_wide.h"
 
 namespace {
 
@@ -30,28 +31,42 @@ int fail(int code, const std::string& msg) {
 }
 
 struct Geom {
-    int rows, cols, cells, A, nsym, max_depth, default_max_plies, hist, planes, hist_cap;
+    int rows, cols, cells, A, nsym, max_depth, default_max_plies, hist, planes, hist_cap, node_bytes, words;
 };
+
+template <class G>
+Geom wide_geom() {
+    return { G::ROWS, G::COLS, G::CELLS, G::A, G::NSYM, G::MAX_DEPTH, G::GAME_MAX_DEPTH + 2, G::HIST, G::PLANES,
+             G::HIST_CAP, G::NODE_BYTES, G::WORDS };
+}
 
 Geom geom_of(int game) {
     if (game == SPRL_CONNECT_FOUR)
         return { ConnectFour::ROWS, ConnectFour::COLS, ConnectFour::CELLS, ConnectFour::A, ConnectFour::NSYM,
-                 ConnectFour::MAX_DEPTH, 48, 1, 3, 1 };
+                 ConnectFour::MAX_DEPTH, 48, 1, 3, 1, SPRL_NODE_BYTES, 1 };
     if (game == SPRL_GO7)
         return { Go7::ROWS, Go7::COLS, Go7::CELLS, Go7::A, Go7::NSYM, Go7::MAX_DEPTH, Go7::GAME_MAX_DEPTH + 2, Go7::HIST,
-                 Go7::PLANES, Go7::HIST_CAP };
-    return { Othello::ROWS, Othello::COLS, Othello::CELLS, Othello::A, Othello::NSYM, Othello::MAX_DEPTH, 128, 1, 3, 1 };
+                 Go7::PLANES, Go7::HIST_CAP, SPRL_NODE_BYTES, 1 };
+    if (game == SPRL_GO9) return wide_geom<GoN<9>>();
+    if (game == SPRL_GO7_WIDE) return wide_geom<GoN<7>>();
+    return { Othello::ROWS, Othello::COLS, Othello::CELLS, Othello::A, Othello::NSYM, Othello::MAX_DEPTH, 128, 1, 3, 1,
+             SPRL_NODE_BYTES, 1 };
 }
 
+bool is_go(int game) { return game == SPRL_GO7 || game == SPRL_GO9 || game == SPRL_GO7_WIDE; }
+bool known_game(int game) { return game == SPRL_OTHELLO || game == SPRL_CONNECT_FOUR || is_go(game); }
+
 int map_cell(int game, int sym, int cell) {
-    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_cell(sym, cell)
-           : game == SPRL_GO7        ? Go7::map_cell(sym, cell)
-                                     : Othello::map_cell(sym, cell);
+    return game == SPRL_CONNECT_FOUR                     ? ConnectFour::map_cell(sym, cell)
+           : (game == SPRL_GO7 || game == SPRL_GO7_WIDE) ? Go7::map_cell(sym, cell)
+           : game == SPRL_GO9                            ? GoN<9>::map_cell(sym, cell)
+                                                         : Othello::map_cell(sym, cell);
 }
 int map_action(int game, int sym, int a) {
-    return game == SPRL_CONNECT_FOUR ? ConnectFour::map_action(sym, a)
-           : game == SPRL_GO7        ? Go7::map_action(sym, a)
-                                     : Othello::map_action(sym, a);
+    return game == SPRL_CONNECT_FOUR                     ? ConnectFour::map_action(sym, a)
+           : (game == SPRL_GO7 || game == SPRL_GO7_WIDE) ? Go7::map_action(sym, a)
+           : game == SPRL_GO9                            ? GoN<9>::map_action(sym, a)
+                                                         : Othello::map_action(sym, a);
 }
 
 // LibTorch-ROCm evaluator plugin (libsprl_amd_torch.so), resolved lazily so the core has no torch dependency
@@ -161,16 +176,16 @@ int sprl_device_available(void) {
 }
 
 int sprl_config_default(int32_t game, sprl_config* cfg) {
-    if (!cfg || (game != SPRL_OTHELLO && game != SPRL_CONNECT_FOUR && game != SPRL_GO7)) return fail(SPRL_E_CONFIG, "unknown game");
+    if (!cfg || !known_game(game)) return fail(SPRL_E_CONFIG, "unknown game");
     memset(cfg, 0, sizeof(*cfg));
     cfg->game = game;
     cfg->device = 0;
     cfg->concurrent_games = 4096;
     cfg->num_traversals = 800;
-    cfg->max_batch = game == SPRL_GO7 ? 16 : 8;           // OTHWorker.cpp:24, C4Worker.cpp:23, GoWorker.cpp:23
-    cfg->max_queue = game == SPRL_GO7 ? 8 : 4;            // OTHWorker.cpp:25, C4Worker.cpp:24, GoWorker.cpp:24
+    cfg->max_batch = is_go(game) ? 16 : 8;           // OTHWorker.cpp:24, C4Worker.cpp:23, GoWorker.cpp:23
+    cfg->max_queue = is_go(game) ? 8 : 4;             // OTHWorker.cpp:25, C4Worker.cpp:24, GoWorker.cpp:24
     cfg->dir_eps = 0.25f;                                 // OTHWorker.cpp:27, C4Worker.cpp:26, GoWorker.cpp:26
-    cfg->dir_alpha = game == SPRL_OTHELLO ? 0.3f : (game == SPRL_GO7 ? 0.2f : 0.5f);   // :28 / :27 / GoWorker.cpp:27
+    cfg->dir_alpha = game == SPRL_OTHELLO ? 0.3f : (is_go(game) ? 0.2f : 0.5f);   // :28 / :27 / GoWorker.cpp:27
     cfg->u_weight = 1.1f;                                 // constants.hpp:6
     cfg->early_cutoff = 15;                               // constants.hpp:8
     cfg->early_exp = 0.98f;                               // constants.hpp:9
@@ -186,8 +201,7 @@ int sprl_config_default(int32_t game, sprl_config* cfg) {
 int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     if (!cfg || !out) return fail(SPRL_E_CONFIG, "null argument");
     *out = nullptr;
-    if (cfg->game != SPRL_OTHELLO && cfg->game != SPRL_CONNECT_FOUR && cfg->game != SPRL_GO7)
-        return fail(SPRL_E_CONFIG, "unknown game");
+    if (!known_game(cfg->game)) return fail(SPRL_E_CONFIG, "unknown game");
     if (cfg->concurrent_games < 1) return fail(SPRL_E_CONFIG, "concurrent_games must be >= 1");
     if (cfg->num_traversals < 1) return fail(SPRL_E_CONFIG, "num_traversals must be >= 1");
     if (cfg->max_batch < 1) return fail(SPRL_E_CONFIG, "max_batch must be >= 1");
@@ -233,7 +247,7 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     const size_t nq = (size_t)P.num_slots * (size_t)P.max_queue;   // dense network batch: slot-major, queue-minor
     const size_t npaths = (size_t)P.num_slots * SPRL_MAXQ;
     bool ok = true;
-    ok = ok && (P.arenas = (uint8_t*)dev_alloc(e, arenas * (size_t)P.node_cap * SPRL_NODE_BYTES));
+    ok = ok && (P.arenas = (uint8_t*)dev_alloc(e, arenas * (size_t)P.node_cap * (size_t)e->g.node_bytes));
     ok = ok && (P.arena_used = (uint32_t*)dev_alloc(e, arenas * sizeof(uint32_t)));
     ok = ok && (P.ctl = (GameCtl*)dev_alloc(e, (size_t)P.num_slots * sizeof(GameCtl)));
     ok = ok && (P.paths = (uint32_t*)dev_alloc(e, npaths * (size_t)P.max_depth * sizeof(uint32_t)));
@@ -244,7 +258,7 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     ok = ok && (e->nn_logits = (float*)dev_alloc(e, nq * (size_t)e->g.A * sizeof(float)));
     ok = ok && (e->nn_value = (float*)dev_alloc(e, nq * sizeof(float)));
     ok = ok && (P.counters = (Counters*)dev_alloc(e, sizeof(Counters)));
-    ok = ok && (P.hist_boards = (uint64_t*)dev_alloc(e, (size_t)P.num_slots * (size_t)e->g.hist_cap * 2 * sizeof(uint64_t)));
+    ok = ok && (P.hist_boards = (uint64_t*)dev_alloc(e, (size_t)P.num_slots * (size_t)e->g.hist_cap * 2 * (size_t)e->g.words * sizeof(uint64_t)));
     if (!ok) {
         std::string m = std::string("device allocation failed (") + be::last_error() + ")";
         sprl_engine_destroy(e);
@@ -327,7 +341,7 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
     if (num_games > e->num_games || !P.rec_boards) {
         // earlier record buffers stay in `allocs` and are released at destroy; runs normally reuse the size
         bool ok = true;
-        ok = ok && (P.rec_boards = (uint64_t*)dev_alloc(e, np * 2 * sizeof(uint64_t)));
+        ok = ok && (P.rec_boards = (uint64_t*)dev_alloc(e, np * 2 * (size_t)e->g.words * sizeof(uint64_t)));
         ok = ok && (P.rec_movers = (uint8_t*)dev_alloc(e, np));
         ok = ok && (P.rec_pdf = (float*)dev_alloc(e, np * (size_t)e->g.A * sizeof(float)));
         ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
@@ -437,7 +451,8 @@ int sprl_engine_collect(sprl_engine* e, sprl_records* out) {
     const size_t np = (size_t)ng * (size_t)P.max_plies;
     std::vector<int32_t> nplies((size_t)ng);
     std::vector<int8_t> winners((size_t)ng);
-    std::vector<uint64_t> boards(np * 2);
+    const size_t WDS = (size_t)g.words;
+    std::vector<uint64_t> boards(np * 2 * WDS);
     std::vector<uint8_t> movers(np);
     std::vector<float> pdfs(np * (size_t)g.A);
     int rc = be::sync();
@@ -467,9 +482,11 @@ int sprl_engine_collect(sprl_engine* e, sprl_records* out) {
         for (int p = 0; p < nplies[(size_t)i]; ++p) {
             const size_t src = (size_t)i * (size_t)P.max_plies + (size_t)p;
             const size_t dst = (size_t)o->ply_offset[(size_t)i] + (size_t)p;
-            const uint64_t p0 = boards[src * 2], p1 = boards[src * 2 + 1];
+            const uint64_t* p0 = &boards[src * 2 * WDS];
+            const uint64_t* p1 = p0 + WDS;
             int8_t* b = &o->boards[dst * (size_t)g.cells];
-            for (int c = 0; c < g.cells; ++c) b[c] = ((p0 >> c) & 1) ? 0 : (((p1 >> c) & 1) ? 1 : -1);
+            for (int c = 0; c < g.cells; ++c)
+                b[c] = ((p0[c >> 6] >> (c & 63)) & 1) ? 0 : (((p1[c >> 6] >> (c & 63)) & 1) ? 1 : -1);
             o->movers[dst] = (int8_t)movers[src];
             memcpy(&o->pdfs[dst * (size_t)g.A], &pdfs[src * (size_t)g.A], (size_t)g.A * sizeof(float));
         }

@@ -64,6 +64,7 @@ GAME_SHAPES = {
     "othello": (8, 8, 65, 1),
     "connect_four": (6, 7, 7, 1),
     "go7": (7, 7, 50, 8),                 # GoNode.hpp:16-19
+    "go9": (9, 9, 82, 8),
 }
 
 

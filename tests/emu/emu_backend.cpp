@@ -10,6 +10,7 @@
 
 #include "../../sprl_amd/csrc/backend.h"
 #include "../../sprl_amd/csrc/step_kernel.h"
+#include "../../sprl_amd/csrc/step_kernel_wide.h"
 
 namespace emu {
 typedef void (*block_fn)(void* arg, int block);
@@ -17,13 +18,19 @@ void launch(block_fn fn, void* arg, int nblocks);
 }
 
 namespace {
-alignas(16) static thread_local unsigned char tl_lds[16384];
+alignas(16) static thread_local unsigned char tl_lds[65536];
 
 template <class G>
 void block_entry(void* arg, int block) {
     const EngineParams* P = (const EngineParams*)arg;
     static_assert(sizeof(sprl::WaveLds<G>) <= sizeof(tl_lds), "emulated LDS too small");
     sprl::step_game<G>(*P, block, reinterpret_cast<sprl::WaveLds<G>*>(tl_lds));
+}
+template <class G>
+void block_entry_wide(void* arg, int block) {
+    const EngineParams* P = (const EngineParams*)arg;
+    static_assert(sizeof(sprlw::WaveLdsW<G>) <= sizeof(tl_lds), "emulated LDS too small");
+    sprlw::step_game<G>(*P, block, reinterpret_cast<sprlw::WaveLdsW<G>*>(tl_lds));
 }
 }  // namespace
 
@@ -42,6 +49,8 @@ int launch_step(int game, const EngineParams& P) {
     EngineParams copy = P;
     if (game == SPRL_GAME_OTHELLO) emu::launch(block_entry<Othello>, &copy, P.num_slots);
     else if (game == SPRL_GAME_GO7) emu::launch(block_entry<Go7>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO9) emu::launch(block_entry_wide<GoN<9>>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO7W) emu::launch(block_entry_wide<GoN<7>>, &copy, P.num_slots);
     else emu::launch(block_entry<ConnectFour>, &copy, P.num_slots);
     return 0;
 }

@@ -81,6 +81,36 @@ def test_go7_network_path_toy_forward(emu):
     assert states.shape[1:] == (17, 7, 7)
 
 
+def test_wide_kernel_at_reference_size(emu):
+    """The multi-strip kernel (step_kernel_wide.h) on Go 7x7, where the oracle is pinned to the reference build."""
+    parity.check_case(emu, "go7_wide", 2, concurrent_games=2, num_traversals=40)
+
+
+def test_go9_two_strip_rows(emu):
+    """Go 9x9 (BASELINE config 4 geometry): 81 points + pass = rows of two wavefront strips, 2-word bit boards."""
+    rec, st = parity.check_case(emu, "go9", 2, concurrent_games=2, num_traversals=40)
+    assert rec.cells == 81 and rec.actions == 82 and rec.planes == 17
+    rec, st = parity.check_case(emu, "go9", 2, concurrent_games=2, num_traversals=60, node_cap=200, spare_arenas=2, seed=9)
+    assert st["compactions"] > 0
+
+
+def test_go9_network_path_toy_forward(emu):
+    A = 82
+
+    def engine_forward(planes_ptr, batch, logits_ptr, value_ptr):
+        planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_float)), shape=(batch, 17, 9, 9))
+        lo, va = parity.toy_forward_numpy(planes, A)
+        np.ctypeslib.as_array(C.cast(logits_ptr, C.POINTER(C.c_float)), shape=(batch, A))[:] = lo
+        np.ctypeslib.as_array(C.cast(value_ptr, C.POINTER(C.c_float)), shape=(batch,))[:] = va
+        return 0
+
+    cfg, rec, st = parity.run_engine(emu, "go9", 2, forward=engine_forward, concurrent_games=2, num_traversals=24, seed=5)
+    cb = po.make_forward(lambda x: parity.toy_forward_numpy(x, A), po.GAME_GO9)
+    ora = po.selfplay(parity.oracle_config("go9", cfg, po.EVAL_CALLBACK, forward=cb), 2, 5, 1, True)
+    parity.assert_same_games(rec, ora)
+    parity.assert_same_counters(st, ora["stats"])
+
+
 def test_more_games_than_slots_and_stream_base(emu):
     rec, st = parity.check_case(emu, "c4", 5, concurrent_games=2, num_traversals=30, seed=99, stream_base=17)
     assert rec.num_games == 5 and st["games"] == 5

@@ -61,6 +61,17 @@ def test_go7_compaction(lib):
     assert st["compactions"] > 0
 
 
+def test_wide_kernel_go7_and_go9(lib):
+    """Multi-strip kernel: at the reference-pinned 7x7 size and at 9x9 (BASELINE config 4 geometry: 1600 traversals,
+    batch 16 / queue 8, D4)."""
+    parity.check_case(lib, "go7_wide", 4, concurrent_games=4, num_traversals=200)
+    rec, st = parity.check_case(lib, "go9", 4, concurrent_games=4, num_traversals=1600, seed=12)
+    assert rec.cells == 81
+    parity.check_case(lib, "go9", 64, concurrent_games=64, num_traversals=48, seed=3)
+    rec, st = parity.check_case(lib, "go9", 4, concurrent_games=4, num_traversals=64, node_cap=300, spare_arenas=4)
+    assert st["compactions"] > 0
+
+
 def test_compaction_tiny_arena(lib):
     rec, st = parity.check_case(lib, "othello", 4, concurrent_games=4, num_traversals=60, node_cap=160, spare_arenas=4)
     assert st["compactions"] > 0
