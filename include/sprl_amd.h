@@ -32,7 +32,7 @@ extern "C" {
 enum { SPRL_OTHELLO = 0, SPRL_CONNECT_FOUR = 1, SPRL_GO7 = 2,
        /* the same Go rules at 9x9 (komi 7.5), rows of two wavefront strips (wide kernel); SPRL_GO7_WIDE runs the
         * reference-size game through that wide kernel (validation of the generic code path) */
-       SPRL_GO9 = 3, SPRL_GO7_WIDE = 5 };
+       SPRL_GO9 = 3, SPRL_GO19 = 4 /* 19x19, rows of six strips */, SPRL_GO7_WIDE = 5 };
 /* evaluator kinds: the reference's RandomNetwork (networks/RandomNetwork.hpp:15-57), OthelloHeuristic
  * (networks/OthelloHeuristic.cpp:5-53) and GridNetwork on a traced TorchScript file
  * (networks/GridNetwork.hpp:37-145) */
@@ -44,7 +44,7 @@ enum { SPRL_MASK_REFERENCE = 0, SPRL_MASK_SYMMETRISED = 1 };
 /* Replaces the compile-time constants of OTHWorker.cpp:12-28 / C4Worker.cpp:11-27 / constants.hpp:4-10
  * and the arguments of runIteration (selfplay/SelfPlay.hpp:204-209). */
 typedef struct sprl_config {
-    int32_t game;              /* SPRL_OTHELLO | SPRL_CONNECT_FOUR | SPRL_GO7 | SPRL_GO9 | SPRL_GO7_WIDE */
+    int32_t game;              /* SPRL_OTHELLO | SPRL_CONNECT_FOUR | SPRL_GO7 | SPRL_GO9 | SPRL_GO19 | SPRL_GO7_WIDE */
     int32_t device;            /* HIP device ordinal */
     int32_t concurrent_games;  /* game slots resident in HBM (one wavefront each) */
     int32_t num_traversals;    /* UCT traversals per move, lower bound (SelfPlay.hpp:100) */

@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "liboracle.so")
 
-GAME_OTHELLO, GAME_C4, GAME_GO7, GAME_GO9 = 0, 1, 2, 3
+GAME_OTHELLO, GAME_C4, GAME_GO7, GAME_GO9, GAME_GO19 = 0, 1, 2, 3, 4
 EVAL_RANDOM, EVAL_HEURISTIC, EVAL_CALLBACK = 0, 1, 2
 MATH_LIBM, MATH_PORTABLE = 0, 1
 MASK_REFERENCE, MASK_SYMMETRISED = 0, 1
@@ -88,7 +88,8 @@ def vp(a):
 GEOM = {GAME_OTHELLO: dict(rows=8, cols=8, cells=64, A=65, nsym=8, hist=1),
         GAME_C4: dict(rows=6, cols=7, cells=42, A=7, nsym=2, hist=1),
         GAME_GO7: dict(rows=7, cols=7, cells=49, A=50, nsym=8, hist=8),
-        GAME_GO9: dict(rows=9, cols=9, cells=81, A=82, nsym=8, hist=8)}
+        GAME_GO9: dict(rows=9, cols=9, cells=81, A=82, nsym=8, hist=8),
+        GAME_GO19: dict(rows=19, cols=19, cells=361, A=362, nsym=8, hist=8)}
 
 # the reference workers' constants: OTHWorker.cpp:24-28, C4Worker.cpp:23-27, constants.hpp:6-10
 DEFAULTS = {
@@ -96,6 +97,7 @@ DEFAULTS = {
     GAME_C4: dict(max_batch=8, max_queue=4, dir_eps=0.25, dir_alpha=0.5),
     GAME_GO7: dict(max_batch=16, max_queue=8, dir_eps=0.25, dir_alpha=0.2),     # GoWorker.cpp:23-27
     GAME_GO9: dict(max_batch=16, max_queue=8, dir_eps=0.25, dir_alpha=0.2),
+    GAME_GO19: dict(max_batch=16, max_queue=8, dir_eps=0.25, dir_alpha=0.2),
 }
 
 
@@ -140,7 +142,7 @@ def make_forward(fn, game):
 def selfplay(cfg, num_games, seed, stream_base=1, per_game_stream=True, cap=None):
     g = GEOM[cfg.game]
     if cap is None:
-        cap = num_games * 130 * (g["nsym"] if cfg.use_sym else 1)
+        cap = num_games * (2 * g["cells"] + 4) * (g["nsym"] if cfg.use_sym else 1)
     boards = np.zeros((cap, g["hist"] * g["cells"]), np.int8)
     players = np.zeros(cap, np.int8)
     sizes = np.zeros(cap, np.int8)

@@ -28,6 +28,8 @@ static geom_t geom(int game) {
         g.rows = 7; g.cols = 7; g.cells = 49; g.A = 50; g.nsym = 8; g.hist = 8;
     } else if (game == ORC_GAME_GO9) {   /* the same rules at width 9 (BASELINE config 4; not reference-pinned) */
         g.rows = 9; g.cols = 9; g.cells = 81; g.A = 82; g.nsym = 8; g.hist = 8;
+    } else if (game == ORC_GAME_GO19) {  /* width 19 (BASELINE config 5) */
+        g.rows = 19; g.cols = 19; g.cells = 361; g.A = 362; g.nsym = 8; g.hist = 8;
     } else {                             /* games/OthelloNode.hpp:8-11 */
         g.rows = 8; g.cols = 8; g.cells = 64; g.A = 65; g.nsym = 8; g.hist = 1;
     }
@@ -297,7 +299,7 @@ static void c4_step(const int8_t* board, int player, const float* mask, int acti
 /* ------------------------------------------------------------------------------------------ */
 /* The reference fixes the board at 7x7 (GoNode.hpp:16); 9x9 is the same code with the width as a parameter
  * (komi 7.5 there, games/GoDesc.md:127-128).  Only the 7x7 instance is pinned against the reference build. */
-#define GO_NMAX 81
+#define GO_NMAX 361                             /* 19x19: index types widened to int16 */
 #define GO_W (s->w)
 #define GO_N (s->w * s->w)
 #define GO_PASS GO_N
@@ -307,8 +309,8 @@ static void c4_step(const int8_t* board, int player, const float* mask, int acti
 typedef struct {
     int w;                                       /* board width */
     int8_t board[GO_NMAX];
-    int8_t dsu[GO_NMAX];                         /* utils/DSU.hpp (path compression omitted: same sets) */
-    int8_t libs[GO_NMAX];                        /* valid at group roots */
+    int16_t dsu[GO_NMAX];                        /* utils/DSU.hpp (path compression omitted: same sets) */
+    int16_t libs[GO_NMAX];                       /* valid at group roots */
     uint64_t comp[GO_NMAX];                      /* per-group Zobrist value, valid at group roots */
     uint64_t hash;
     int depth;
@@ -364,7 +366,7 @@ static int go_compute_liberties(const go_state* s, int coord) {              /* 
 }
 static void go_clear_component(go_state* s, int coord, int piece) {          /* GoNode.cpp:54-94 */
     s->board[coord] = -1;
-    s->dsu[coord] = (int8_t)coord;
+    s->dsu[coord] = (int16_t)coord;
     s->libs[go_find(s, coord)] = 0;
     s->comp[go_find(s, coord)] = 0;
     int groups[4], ng = 0, nb[4];
@@ -395,11 +397,11 @@ static void go_place(go_state* s, int coord, int piece) {                    /* 
             if (go_find(s, n) == go_find(s, coord)) continue;
             new_comp ^= s->comp[go_find(s, n)];
             int rx = go_find(s, n), ry = go_find(s, coord);                  /* DSU::unite(neighbor, coord) */
-            if (rx != ry) s->dsu[rx] = (int8_t)ry;
+            if (rx != ry) s->dsu[rx] = (int16_t)ry;
         }
     }
     s->comp[go_find(s, coord)] = new_comp;
-    s->libs[go_find(s, coord)] = (int8_t)go_compute_liberties(s, coord);
+    s->libs[go_find(s, coord)] = (int16_t)go_compute_liberties(s, coord);
     uint64_t update = go_zobrist(coord, piece);
     int groups[4], ng = 0;
     for (int i = 0; i < k; ++i) {
@@ -474,7 +476,7 @@ static void go_start(go_state* s, int width) {                               /* 
     memset(s, 0, sizeof(*s));
     s->w = width;
     memset(s->board, -1, GO_NMAX);
-    for (int i = 0; i < GO_NMAX; ++i) s->dsu[i] = (int8_t)i;
+    for (int i = 0; i < GO_NMAX; ++i) s->dsu[i] = (int16_t)i;
 }
 static void go_next(const go_state* p, int player, int action, go_state* c, float* mask, int* terminal,
                     int* winner) {                                           /* GoNode.cpp:319-383 */
@@ -505,7 +507,7 @@ void orc_start(int game, int8_t* board, int* player, float* mask) {
     *player = 0;
     if (game == ORC_GAME_C4) {                                               /* ConnectFourNode.cpp:13-21 */
         for (int a = 0; a < 7; ++a) mask[a] = 1.0f;
-    } else if (game == ORC_GAME_GO7 || game == ORC_GAME_GO9) {               /* GoNode.cpp:306 */
+    } else if (game == ORC_GAME_GO7 || game == ORC_GAME_GO9 || game == ORC_GAME_GO19) {               /* GoNode.cpp:306 */
         for (int a = 0; a < g.A; ++a) mask[a] = 1.0f;
     } else {                                                                 /* OthelloNode.cpp:18-32 */
         board[3 * 8 + 3] = 1;
@@ -538,7 +540,7 @@ int orc_playout(int game, uint64_t seed, int stream, int max_plies, int8_t* boar
     int player, term = 0, winner = -1, ply = 0;
     go_state* gs = NULL;
     orc_start(game, b, &player, m);
-    if (game == ORC_GAME_GO7 || game == ORC_GAME_GO9) {
+    if (game == ORC_GAME_GO7 || game == ORC_GAME_GO9 || game == ORC_GAME_GO19) {
         gs = (go_state*)malloc(sizeof(go_state) * (size_t)(max_plies + 1));
         go_start(&gs[0], g.cols);
     }
@@ -758,7 +760,7 @@ static node* node_new(tree* t, node* parent, int action) {
         n->own_W = &parent->W[action];
     } else {
         orc_start(t->cfg->game, n->board, &n->player, n->mask);
-        if (t->cfg->game == ORC_GAME_GO7 || t->cfg->game == ORC_GAME_GO9) {
+        if (t->cfg->game == ORC_GAME_GO7 || t->cfg->game == ORC_GAME_GO9 || t->cfg->game == ORC_GAME_GO19) {
             n->go = (go_state*)malloc(sizeof(go_state));
             go_start(n->go, t->g.cols);
         }

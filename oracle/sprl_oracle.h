@@ -26,10 +26,10 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_A 128
-#define ORC_MAX_CELLS 128
+#define ORC_MAX_A 384
+#define ORC_MAX_CELLS 384
 
-enum { ORC_GAME_OTHELLO = 0, ORC_GAME_C4 = 1, ORC_GAME_GO7 = 2, ORC_GAME_GO9 = 3 };
+enum { ORC_GAME_OTHELLO = 0, ORC_GAME_C4 = 1, ORC_GAME_GO7 = 2, ORC_GAME_GO9 = 3, ORC_GAME_GO19 = 4 };
 #define ORC_MAX_HIST 8
 enum { ORC_EVAL_RANDOM = 0, ORC_EVAL_HEURISTIC = 1, ORC_EVAL_CALLBACK = 2 };
 enum { ORC_MATH_LIBM = 0, ORC_MATH_PORTABLE = 1 };

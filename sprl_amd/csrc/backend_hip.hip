@@ -134,6 +134,7 @@ int launch_step(int game, const EngineParams& P) {
     if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(step_kernel<Othello>, grid, block, 0, 0, P);
     else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(step_kernel<Go7>, grid, block, 0, 0, P);
     else if (game == SPRL_GAME_GO9) hipLaunchKernelGGL(step_kernel_wide<GoN<9>>, grid, block, 0, 0, P);
+    else if (game == SPRL_GAME_GO19) hipLaunchKernelGGL(step_kernel_wide<GoN<19>>, grid, block, 0, 0, P);
     else if (game == SPRL_GAME_GO7W) hipLaunchKernelGGL(step_kernel_wide<GoN<7>>, grid, block, 0, 0, P);
     else hipLaunchKernelGGL(step_kernel<ConnectFour>, grid, block, 0, 0, P);
     return ok(hipGetLastError(), "step_kernel launch") ? 0 : -1;

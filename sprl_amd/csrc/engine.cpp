@@ -48,24 +48,27 @@ Geom geom_of(int game) {
         return { Go7::ROWS, Go7::COLS, Go7::CELLS, Go7::A, Go7::NSYM, Go7::MAX_DEPTH, Go7::GAME_MAX_DEPTH + 2, Go7::HIST,
                  Go7::PLANES, Go7::HIST_CAP, SPRL_NODE_BYTES, 1 };
     if (game == SPRL_GO9) return wide_geom<GoN<9>>();
+    if (game == SPRL_GO19) return wide_geom<GoN<19>>();
     if (game == SPRL_GO7_WIDE) return wide_geom<GoN<7>>();
     return { Othello::ROWS, Othello::COLS, Othello::CELLS, Othello::A, Othello::NSYM, Othello::MAX_DEPTH, 128, 1, 3, 1,
              SPRL_NODE_BYTES, 1 };
 }
 
-bool is_go(int game) { return game == SPRL_GO7 || game == SPRL_GO9 || game == SPRL_GO7_WIDE; }
+bool is_go(int game) { return game == SPRL_GO7 || game == SPRL_GO9 || game == SPRL_GO19 || game == SPRL_GO7_WIDE; }
 bool known_game(int game) { return game == SPRL_OTHELLO || game == SPRL_CONNECT_FOUR || is_go(game); }
 
 int map_cell(int game, int sym, int cell) {
     return game == SPRL_CONNECT_FOUR                     ? ConnectFour::map_cell(sym, cell)
            : (game == SPRL_GO7 || game == SPRL_GO7_WIDE) ? Go7::map_cell(sym, cell)
            : game == SPRL_GO9                            ? GoN<9>::map_cell(sym, cell)
+           : game == SPRL_GO19                           ? GoN<19>::map_cell(sym, cell)
                                                          : Othello::map_cell(sym, cell);
 }
 int map_action(int game, int sym, int a) {
     return game == SPRL_CONNECT_FOUR                     ? ConnectFour::map_action(sym, a)
            : (game == SPRL_GO7 || game == SPRL_GO7_WIDE) ? Go7::map_action(sym, a)
            : game == SPRL_GO9                            ? GoN<9>::map_action(sym, a)
+           : game == SPRL_GO19                           ? GoN<19>::map_action(sym, a)
                                                          : Othello::map_action(sym, a);
 }
 

@@ -361,7 +361,6 @@ SPRL_DEV void finish_leaves(const EngineParams& P, GameW& g, int slot, GameCtl* 
 
 template <class G>
 SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* ctl, WaveLdsW<G>* lds) {
-    using BB = Bits<G::WORDS>;
     const int l = wv::lane();
     int trav = 0;
     while (trav < P.max_batch) {

@@ -12,10 +12,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libsprl_amd.so")
 
-OTHELLO, CONNECT_FOUR, GO7, GO9, GO7_WIDE = 0, 1, 2, 3, 5
+OTHELLO, CONNECT_FOUR, GO7, GO9, GO19, GO7_WIDE = 0, 1, 2, 3, 4, 5
 EVAL_RANDOM, EVAL_HEURISTIC, EVAL_NETWORK = 0, 1, 2
 MASK_REFERENCE, MASK_SYMMETRISED = 0, 1
-GAME_IDS = {"othello": OTHELLO, "connect_four": CONNECT_FOUR, "c4": CONNECT_FOUR, "go": GO7, "go7": GO7, "go9": GO9,
+GAME_IDS = {"othello": OTHELLO, "connect_four": CONNECT_FOUR, "c4": CONNECT_FOUR, "go": GO7, "go7": GO7, "go9": GO9, "go19": GO19,
             "go7_wide": GO7_WIDE}
 
 

@@ -65,6 +65,7 @@ GAME_SHAPES = {
     "connect_four": (6, 7, 7, 1),
     "go7": (7, 7, 50, 8),                 # GoNode.hpp:16-19
     "go9": (9, 9, 82, 8),
+    "go19": (19, 19, 362, 8),
 }
 
 

@@ -18,7 +18,7 @@ void launch(block_fn fn, void* arg, int nblocks);
 }
 
 namespace {
-alignas(16) static thread_local unsigned char tl_lds[65536];
+alignas(16) static thread_local unsigned char tl_lds[160 * 1024];
 
 template <class G>
 void block_entry(void* arg, int block) {
@@ -50,6 +50,7 @@ int launch_step(int game, const EngineParams& P) {
     if (game == SPRL_GAME_OTHELLO) emu::launch(block_entry<Othello>, &copy, P.num_slots);
     else if (game == SPRL_GAME_GO7) emu::launch(block_entry<Go7>, &copy, P.num_slots);
     else if (game == SPRL_GAME_GO9) emu::launch(block_entry_wide<GoN<9>>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO19) emu::launch(block_entry_wide<GoN<19>>, &copy, P.num_slots);
     else if (game == SPRL_GAME_GO7W) emu::launch(block_entry_wide<GoN<7>>, &copy, P.num_slots);
     else emu::launch(block_entry<ConnectFour>, &copy, P.num_slots);
     return 0;

@@ -5,7 +5,7 @@ import numpy as np
 from oracle import pyoracle as po
 from sprl_amd import engine as E
 
-OGAME = {"othello": po.GAME_OTHELLO, "c4": po.GAME_C4, "go": po.GAME_GO7, "go7_wide": po.GAME_GO7, "go9": po.GAME_GO9}
+OGAME = {"othello": po.GAME_OTHELLO, "c4": po.GAME_C4, "go": po.GAME_GO7, "go7_wide": po.GAME_GO7, "go9": po.GAME_GO9, "go19": po.GAME_GO19}
 
 
 def oracle_config(game, cfg, kind, forward=None):

@@ -94,6 +94,12 @@ def test_go9_two_strip_rows(emu):
     assert st["compactions"] > 0
 
 
+def test_go19_six_strip_rows(emu):
+    """Go 19x19 (BASELINE config 5 geometry): 361 points + pass, rows of six strips, 6-word bit boards."""
+    rec, st = parity.check_case(emu, "go19", 1, concurrent_games=1, num_traversals=8, seed=4)
+    assert rec.cells == 361 and rec.actions == 362
+
+
 def test_go9_network_path_toy_forward(emu):
     A = 82
 

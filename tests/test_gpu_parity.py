@@ -72,6 +72,12 @@ def test_wide_kernel_go7_and_go9(lib):
     assert st["compactions"] > 0
 
 
+def test_go19(lib):
+    """Go 19x19 geometry (BASELINE config 5): 6-strip rows; short budget, whole games."""
+    rec, st = parity.check_case(lib, "go19", 2, concurrent_games=2, num_traversals=64, seed=8)
+    assert rec.cells == 361 and rec.planes == 17
+
+
 def test_compaction_tiny_arena(lib):
     rec, st = parity.check_case(lib, "othello", 4, concurrent_games=4, num_traversals=60, node_cap=160, spare_arenas=4)
     assert st["compactions"] > 0
