@@ -209,6 +209,9 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     if (cfg->num_traversals < 1) return fail(SPRL_E_CONFIG, "num_traversals must be >= 1");
     if (cfg->max_batch < 1) return fail(SPRL_E_CONFIG, "max_batch must be >= 1");
     if (cfg->max_queue < 1 || cfg->max_queue > SPRL_MAXQ) return fail(SPRL_E_CONFIG, "max_queue must be in [1, 8]");
+    if (cfg->num_traversals <= cfg->max_queue)
+        return fail(SPRL_E_CONFIG, "num_traversals must exceed max_queue: a fresh root is queued max_queue times (SURVEY Q7), so "
+                                   "the first move would be sampled from an all-zero visit count (NaN pdf in the reference)");
     if (cfg->stream_base < 1) return fail(SPRL_E_CONFIG, "stream_base must be >= 1 (stream 0 means 'pick one' in the reference)");
     if (cfg->node_cap < 0 || cfg->node_cap > 65535) return fail(SPRL_E_CONFIG, "node_cap must be <= 65535");
     if (!(cfg->dir_alpha > 0.0f)) return fail(SPRL_E_CONFIG, "dir_alpha must be > 0");

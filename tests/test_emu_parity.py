@@ -96,7 +96,7 @@ def test_go9_two_strip_rows(emu):
 
 def test_go19_six_strip_rows(emu):
     """Go 19x19 (BASELINE config 5 geometry): 361 points + pass, rows of six strips, 6-word bit boards."""
-    rec, st = parity.check_case(emu, "go19", 1, concurrent_games=1, num_traversals=8, seed=4)
+    rec, st = parity.check_case(emu, "go19", 1, concurrent_games=1, num_traversals=12, seed=4)
     assert rec.cells == 361 and rec.actions == 362
 
 
@@ -164,7 +164,8 @@ def test_error_codes(emu):
         eng.run(1)
     assert ei.value.code == -3          # SPRL_E_NODEPOOL: live subtree cannot fit 40 nodes
     eng.close()
-    for bad in (dict(max_queue=9), dict(num_traversals=0), dict(stream_base=0), dict(concurrent_games=0)):
+    for bad in (dict(max_queue=9), dict(num_traversals=0), dict(stream_base=0), dict(concurrent_games=0),
+                dict(num_traversals=4, max_queue=4)):
         with pytest.raises(E.SprlError) as ei:
             E.Engine(E.default_config("othello", emu, **bad), emu)
         assert ei.value.code == -1
