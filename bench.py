@@ -224,7 +224,7 @@ def main():
             "data": "synthetic (start-position self-play, random-init weights)",
             "config": {"workload": f"Othello 8x8, {args.traversals} UCT iters/move, {args.concurrent} concurrent games/GPU, "
                                    f"{games} games/GPU/step, batch 8/queue 4, D4, Dirichlet(0.25,0.3)",
-                       "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32 via LibTorch-ROCm" if model_path else args.model),
+                       "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32, " + eng.evaluator_info() if model_path else args.model),
                        "parallelism": f"game-sharded x{world}, RCCL gather of records" if world > 1 else "1 GPU"},
             "expansions_per_sec": d["expansions"] * world / elapsed,
             "traversals_per_sec": d["traversals"] * world / elapsed,

@@ -82,6 +82,9 @@ void sprl_engine_destroy(sprl_engine* e);
  * (networks/GridNetwork.hpp:99-102), which is evaluated on the GPU through LibTorch-ROCm. */
 int sprl_engine_set_model(sprl_engine* e, const char* model);
 
+/* Human-readable description of the evaluator in use (which network execution path was selected). */
+int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len);
+
 /* Alternative evaluator hook: `fn` is called once per search round with DEVICE pointers
  * planes float32[batch][2H+1][R][C] -> logits float32[batch][A], value float32[batch]; it must enqueue its
  * work on the HIP null stream (or synchronise before returning). */

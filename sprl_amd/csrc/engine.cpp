@@ -78,6 +78,7 @@ struct TorchPlugin {
     void* (*load)(const char*, int, char*, int) = nullptr;
     int (*forward)(void*, const float*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
     void (*release)(void*) = nullptr;
+    int (*is_native)(void*) = nullptr;
 };
 
 struct RecordsOwner {
@@ -150,6 +151,7 @@ int load_torch_plugin(sprl_engine* e) {
     e->torch.load = (void* (*)(const char*, int, char*, int))dlsym(lib, "sprl_torch_load");
     e->torch.forward = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, char*, int))dlsym(lib, "sprl_torch_forward");
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
+    e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
     if (!e->torch.load || !e->torch.forward || !e->torch.release)
         return fail(SPRL_E_MODEL, "LibTorch evaluator plugin lacks required symbols");
     return 0;
@@ -326,6 +328,18 @@ int sprl_engine_set_model(sprl_engine* e, const char* model) {
         if (b == max_rows) break;
     }
     be::sync();
+    return 0;
+}
+
+int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len) {
+    if (!e || !buf || len < 1) return fail(SPRL_E_CONFIG, "null argument");
+    const char* what = e->eval_kind == SPRL_EVAL_RANDOM      ? "random (in-kernel)"
+                       : e->eval_kind == SPRL_EVAL_HEURISTIC ? "heuristic (in-kernel)"
+                       : e->forward_cb                      ? "forward callback"
+                       : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model))
+                           ? "LibTorch-ROCm: MIOpen convolutions + fused bias/BN/ReLU epilogue kernel"
+                           : "LibTorch-ROCm: TorchScript graph (bias hoisted for the JIT fuser)";
+    snprintf(buf, (size_t)len, "%s", what);
     return 0;
 }
 

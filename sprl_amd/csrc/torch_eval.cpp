@@ -12,13 +12,96 @@
 #include <torch/torch.h>
 
 #include <cstring>
+#include <map>
 #include <string>
+#include <vector>
+
+extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float* scale, const float* shift,
+                                    int64_t numel, int channels, int hw, void* stream);
 
 namespace {
+// The network of src/networks/grid_networks.py:30-79 with its parameters taken from the traced module, evaluated as
+// MIOpen convolutions (no bias) + one hand-written fused epilogue pass per convolution (cnn_epilogue.hip).
+struct NativeNet {
+    bool ok = false;
+    at::Tensor stem_w, stem_scale, stem_shift;
+    struct Block { at::Tensor w1, s1, t1, w2, s2, t2; };
+    std::vector<Block> blocks;
+    at::Tensor pconv_w, pconv_b, pfc_w, pfc_b, vconv_w, vconv_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b;
+};
+
 struct Model {
     torch::jit::Module module;
     int device = 0;
+    NativeNet native;
 };
+
+// scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta  (BatchNorm2d eval, eps = 1e-5)
+bool fold_bn(const std::map<std::string, at::Tensor>& t, const std::string& conv, const std::string& bn, at::Tensor& w,
+             at::Tensor& scale, at::Tensor& shift) {
+    auto W = t.find(conv + ".weight"), B = t.find(conv + ".bias"), g = t.find(bn + ".weight"), b = t.find(bn + ".bias"),
+         m = t.find(bn + ".running_mean"), v = t.find(bn + ".running_var");
+    if (W == t.end() || B == t.end() || g == t.end() || b == t.end() || m == t.end() || v == t.end()) return false;
+    if (W->second.dim() != 4 || W->second.size(2) != 3 || W->second.size(3) != 3) return false;
+    w = W->second.contiguous();
+    scale = (g->second / at::sqrt(v->second + 1e-5)).contiguous();
+    shift = ((B->second - m->second) * scale + b->second).contiguous();
+    return true;
+}
+
+void build_native(Model* m) {
+    std::map<std::string, at::Tensor> t;
+    for (const auto& p : m->module.named_parameters()) t[p.name] = p.value.detach();
+    for (const auto& b : m->module.named_buffers()) t[b.name] = b.value.detach();
+    NativeNet n;
+    if (!fold_bn(t, "conv", "bn", n.stem_w, n.stem_scale, n.stem_shift)) return;
+    for (int i = 0;; ++i) {
+        const std::string pre = "residual_blocks." + std::to_string(i);
+        if (t.find(pre + ".conv1.weight") == t.end()) break;
+        NativeNet::Block blk;
+        if (!fold_bn(t, pre + ".conv1", pre + ".bn1", blk.w1, blk.s1, blk.t1)) return;
+        if (!fold_bn(t, pre + ".conv2", pre + ".bn2", blk.w2, blk.s2, blk.t2)) return;
+        n.blocks.push_back(blk);
+    }
+    const char* need[] = { "policy_conv.weight", "policy_conv.bias", "policy_fc.weight", "policy_fc.bias", "value_conv.weight",
+                           "value_conv.bias", "value_fc1.weight", "value_fc1.bias", "value_fc2.weight", "value_fc2.bias" };
+    for (const char* k : need)
+        if (t.find(k) == t.end()) return;
+    n.pconv_w = t["policy_conv.weight"]; n.pconv_b = t["policy_conv.bias"];
+    n.pfc_w = t["policy_fc.weight"].t().contiguous(); n.pfc_b = t["policy_fc.bias"];
+    n.vconv_w = t["value_conv.weight"]; n.vconv_b = t["value_conv.bias"];
+    n.vfc1_w = t["value_fc1.weight"].t().contiguous(); n.vfc1_b = t["value_fc1.bias"];
+    n.vfc2_w = t["value_fc2.weight"].t().contiguous(); n.vfc2_b = t["value_fc2.bias"];
+    // every tensor of the traced module must be accounted for, otherwise this is not the architecture we know
+    size_t expected = 6 + n.blocks.size() * 12 + 10 + (1 + 2 * n.blocks.size());   // + num_batches_tracked buffers
+    if (t.size() != expected) return;
+    n.ok = true;
+    m->native = n;
+}
+
+bool epilogue(at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, const at::Tensor* residual) {
+    const int C = (int)x.size(1), hw = (int)(x.size(2) * x.size(3));
+    return sprl_bn_relu_inplace(x.data_ptr<float>(), residual ? residual->data_ptr<float>() : nullptr,
+                                scale.data_ptr<float>(), shift.data_ptr<float>(), x.numel(), C, hw, nullptr) == 0;
+}
+
+bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value) {
+    at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
+    if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
+    for (const auto& b : n.blocks) {
+        at::Tensor y = at::conv2d(x, b.w1, {}, 1, 1);
+        if (!y.is_contiguous() || !epilogue(y, b.s1, b.t1, nullptr)) return false;
+        at::Tensor z = at::conv2d(y, b.w2, {}, 1, 1);
+        if (!z.is_contiguous() || !epilogue(z, b.s2, b.t2, &x)) return false;
+        x = z;
+    }
+    at::Tensor p = at::relu(at::conv2d(x, n.pconv_w, n.pconv_b)).flatten(1);
+    logits = at::addmm(n.pfc_b, p, n.pfc_w);
+    at::Tensor v = at::relu(at::conv2d(x, n.vconv_w, n.vconv_b)).flatten(1);
+    v = at::relu(at::addmm(n.vfc1_b, v, n.vfc1_w));
+    value = at::tanh(at::addmm(n.vfc2_b, v, n.vfc2_w));
+    return true;
+}
 
 // After freezing, every convolution carries its bias as a constant and ATen applies it with a separate full-tensor
 // elementwise kernel (the convolution library does not add it).  Move the bias into an explicit broadcast add right
@@ -74,6 +157,7 @@ void* sprl_torch_load(const char* path, int device, char* err, int errlen) {
         m->module = torch::jit::load(path, device >= 0 ? torch::Device(torch::kCUDA, (c10::DeviceIndex)device)
                                                        : torch::Device(torch::kCPU));
         m->module.eval();                       // GridNetwork.hpp:67
+        if (device >= 0 && !getenv("SPRL_TORCH_NO_NATIVE")) build_native(m);
         if (!getenv("SPRL_TORCH_NO_REWRITE")) {
             try {
                 torch::jit::Module frozen = torch::jit::freeze_module(m->module);
@@ -99,9 +183,12 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
                         ? torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, (c10::DeviceIndex)m->device)
                         : torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCPU);
         auto in = torch::from_blob(const_cast<float*>(planes), { batch, nplanes, rows, cols }, opts);
-        auto out = m->module.forward({ in }).toTuple();             // GridNetwork.hpp:99-102
-        auto lo = out->elements()[0].toTensor();
-        auto va = out->elements()[1].toTensor();
+        at::Tensor lo, va;
+        if (!(m->native.ok && forward_native(m->native, in, lo, va))) {
+            auto out = m->module.forward({ in }).toTuple();         // GridNetwork.hpp:99-102 (generic TorchScript path)
+            lo = out->elements()[0].toTensor();
+            va = out->elements()[1].toTensor();
+        }
         if (lo.numel() != (int64_t)batch * actions || va.numel() != batch) {
             put_err(err, errlen, "model output shape does not match (logits[B,A], value[B,1])");
             return -1;
@@ -116,5 +203,9 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
 }
 
 void sprl_torch_free(void* handle) { delete static_cast<Model*>(handle); }
+
+// 1 when the network was recognised and runs as MIOpen convolutions + the hand-written fused epilogue kernel,
+// 0 when it runs as the generic (rewritten) TorchScript graph
+int sprl_torch_is_native(void* handle) { return static_cast<Model*>(handle)->native.ok ? 1 : 0; }
 
 }  // extern "C"

@@ -98,6 +98,7 @@ def load_library(path=None):
     L.sprl_engine_destroy.restype = None
     L.sprl_engine_set_model.argtypes = [C.c_void_p, C.c_char_p]
     L.sprl_engine_set_forward.argtypes = [C.c_void_p, FORWARD_FN, C.c_void_p]
+    L.sprl_engine_evaluator_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.sprl_engine_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Records)]
     L.sprl_engine_begin.argtypes = [C.c_void_p, C.c_int32]
     L.sprl_engine_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -215,6 +216,11 @@ class Engine:
                 return -1
         self._cb = FORWARD_FN(_cb)
         self._check(self._lib.sprl_engine_set_forward(self._h, self._cb, None))
+
+    def evaluator_info(self):
+        buf = C.create_string_buffer(256)
+        self._check(self._lib.sprl_engine_evaluator_info(self._h, buf, 256))
+        return buf.value.decode()
 
     def run(self, num_games):
         rec = Records()
