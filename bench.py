@@ -156,7 +156,9 @@ def main():
                            num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
                            stream_base=1 + rank * games * (total_steps + 1), profile=0 if args.no_profile else 1)
     eng = E.Engine(cfg, lib)
+    t_load = time.perf_counter()
     eng.set_model(model_path if model_path else args.model)
+    t_load = time.perf_counter() - t_load
 
     def barrier():
         torch.cuda.synchronize()
@@ -233,7 +235,7 @@ def main():
             "search_shape": shape,
             "rank0": {"kernel_ms": d["kernel_ms"], "nn_ms": d["nn_ms"], "kernel_launches": d["kernel_launches"],
                       "rounds": d["rounds"], "nn_batches": d["nn_batches"], "nn_rows": d["nn_rows"],
-                      "nn_fill": d["nn_evals"] / max(1, d["nn_rows"]), "hbm_gib": st1["hbm_bytes"] / 2**30,
+                      "nn_fill": d["nn_evals"] / max(1, d["nn_rows"]), "hbm_gib": st1["hbm_bytes"] / 2**30, "model_load_and_warmup_s": t_load,
                       "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"]},
         }
         if d.get("cyc_total", 0) > 0:

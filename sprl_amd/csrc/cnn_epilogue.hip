@@ -33,7 +33,57 @@ __global__ void __launch_bounds__(256) bn_relu_kernel(float4* __restrict__ x, co
         x[i] = v;
     }
 }
+// Both 1x1 head convolutions (policy: C -> PC channels, value: C -> VC channels; grid_networks.py:44,49) + bias + ReLU in
+// ONE pass over the trunk output: thread = (sample, position), consecutive lanes read consecutive positions of one
+// channel plane (coalesced), the OC = PC + VC weight rows sit in LDS.  Replaces two library convolutions, two bias
+// adds and two ReLUs that would each stream the 64-channel activation again.
+template <int OC>
+__global__ void __launch_bounds__(256) heads_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out_p,
+                                                    float* __restrict__ out_v, int64_t n_pos, int C, int HW, int PC) {
+    extern __shared__ float wsh[];                       // [OC][C] then [OC] biases
+    for (int i = threadIdx.x; i < OC * C + OC; i += blockDim.x) wsh[i] = i < OC * C ? w[i] : bias[i - OC * C];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int pos = (int)(i - b * HW);
+        const float* xp = x + b * (int64_t)C * HW + pos;
+        float acc[OC];
+#pragma unroll
+        for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = xp[(int64_t)c * HW];
+#pragma unroll
+            for (int o = 0; o < OC; ++o) acc[o] += wsh[o * C + c] * v;
+        }
+#pragma unroll
+        for (int o = 0; o < OC; ++o) {
+            float r = acc[o] + wsh[OC * C + o];
+            r = r > 0.0f ? r : 0.0f;
+            if (o < PC) out_p[(b * PC + o) * HW + pos] = r;
+            else out_v[(b * (OC - PC) + (o - PC)) * HW + pos] = r;
+        }
+    }
+}
 }  // namespace
+
+extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const float* bias, float* out_p, float* out_v,
+                                       int64_t batch, int C, int HW, int PC, int VC, void* stream) {
+    const int OC = PC + VC;
+    const int64_t n_pos = batch * HW;
+    int64_t blocks = (n_pos + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const size_t lds = (size_t)(OC * C + OC) * sizeof(float);
+#define LAUNCH(N) hipLaunchKernelGGL(heads_kernel<N>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, w, bias, out_p, out_v, n_pos, C, HW, PC)
+    switch (OC) {
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    default: return -1;
+    }
+#undef LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float* scale, const float* shift,
                                     int64_t numel, int channels, int hw, void* stream) {

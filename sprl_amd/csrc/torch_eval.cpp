@@ -11,6 +11,7 @@
 #include <torch/script.h>
 #include <torch/torch.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -18,6 +19,8 @@
 
 extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float* scale, const float* shift,
                                     int64_t numel, int channels, int hw, void* stream);
+extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const float* bias, float* out_p, float* out_v,
+                                       int64_t batch, int C, int HW, int PC, int VC, void* stream);
 
 namespace {
 // The network of src/networks/grid_networks.py:30-79 with its parameters taken from the traced module, evaluated as
@@ -28,6 +31,8 @@ struct NativeNet {
     struct Block { at::Tensor w1, s1, t1, w2, s2, t2; };
     std::vector<Block> blocks;
     at::Tensor pconv_w, pconv_b, pfc_w, pfc_b, vconv_w, vconv_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b;
+    at::Tensor heads_w, heads_b;     // [PC + VC][C] and [PC + VC]: both 1x1 head convolutions as one fused pass
+    int pc = 0, vc = 0;
 };
 
 struct Model {
@@ -72,6 +77,11 @@ void build_native(Model* m) {
     n.vconv_w = t["value_conv.weight"]; n.vconv_b = t["value_conv.bias"];
     n.vfc1_w = t["value_fc1.weight"].t().contiguous(); n.vfc1_b = t["value_fc1.bias"];
     n.vfc2_w = t["value_fc2.weight"].t().contiguous(); n.vfc2_b = t["value_fc2.bias"];
+    n.pc = (int)n.pconv_w.size(0);
+    n.vc = (int)n.vconv_w.size(0);
+    if (n.pconv_w.size(2) != 1 || n.vconv_w.size(2) != 1 || n.pc + n.vc < 2 || n.pc + n.vc > 4) return;
+    n.heads_w = at::cat({ n.pconv_w.reshape({ n.pc, -1 }), n.vconv_w.reshape({ n.vc, -1 }) }, 0).contiguous();
+    n.heads_b = at::cat({ n.pconv_b, n.vconv_b }, 0).contiguous();
     // every tensor of the traced module must be accounted for, otherwise this is not the architecture we know
     size_t expected = 6 + n.blocks.size() * 12 + 10 + (1 + 2 * n.blocks.size());   // + num_batches_tracked buffers
     if (t.size() != expected) return;
@@ -95,9 +105,14 @@ bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits
         if (!z.is_contiguous() || !epilogue(z, b.s2, b.t2, &x)) return false;
         x = z;
     }
-    at::Tensor p = at::relu(at::conv2d(x, n.pconv_w, n.pconv_b)).flatten(1);
+    const int64_t B = x.size(0);
+    const int C = (int)x.size(1), HW = (int)(x.size(2) * x.size(3));
+    at::Tensor p = at::empty({ B, (int64_t)n.pc * HW }, x.options());
+    at::Tensor v = at::empty({ B, (int64_t)n.vc * HW }, x.options());
+    if (sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
+                                p.data_ptr<float>(), v.data_ptr<float>(), B, C, HW, n.pc, n.vc, nullptr) != 0)
+        return false;
     logits = at::addmm(n.pfc_b, p, n.pfc_w);
-    at::Tensor v = at::relu(at::conv2d(x, n.vconv_w, n.vconv_b)).flatten(1);
     v = at::relu(at::addmm(n.vfc1_b, v, n.vfc1_w));
     value = at::tanh(at::addmm(n.vfc2_b, v, n.vfc2_w));
     return true;
@@ -146,6 +161,10 @@ void put_err(char* err, int errlen, const std::string& msg) {
 extern "C" {
 
 void* sprl_torch_load(const char* path, int device, char* err, int errlen) {
+    // MIOpen's solver search benchmarks its im2col+GEMM family one image at a time (2.2 M tiny launches for our 16
+    // batch shapes, ~20 s) and never picks it for these 3x3 convolutions; leave it out of the search unless the user
+    // has set the variable.
+    setenv("MIOPEN_DEBUG_CONV_GEMM", "0", 0);
     try {
         // device < 0: host tensors — used only by the CPU unit test of the graph rewrite, never by the engine
         if (device >= 0 && !torch::cuda::is_available()) {
