@@ -98,13 +98,24 @@ SPRL_DEV uint32_t shfl_u32(uint32_t v, int src) {
 SPRL_DEV uint32_t bcast_u32(uint32_t v, int src) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
 }
+// Wave-wide max on the VALU's data-parallel-primitive paths (quad_perm, row_mirror, row_bcast): six VALU
+// instructions of a few cycles each, instead of a butterfly of six dependent ds_bpermute round trips through LDS
+// (~100+ cycles each), which sat on the critical path of every level of a descent.
 SPRL_DEV float fmax_all(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
+#define SPRL_DPP_MAX(ctrl, row_mask)                                                                          \
+    {                                                                                                         \
+        const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, row_mask, 0xf, false); \
+        const float f = __int_as_float(o);                                                                    \
+        v = f > v ? f : v;                                                                                    \
     }
-    return v;
+    SPRL_DPP_MAX(0xB1, 0xf)    // quad_perm [1,0,3,2]
+    SPRL_DPP_MAX(0x4E, 0xf)    // quad_perm [2,3,0,1]
+    SPRL_DPP_MAX(0x141, 0xf)   // row_half_mirror
+    SPRL_DPP_MAX(0x140, 0xf)   // row_mirror: every lane of a 16-lane row now holds the row max
+    SPRL_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    SPRL_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave max
+#undef SPRL_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 SPRL_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 SPRL_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
