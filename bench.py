@@ -242,6 +242,7 @@ def main():
             out["phase_cycles_share"] = {k[4:]: d[k] / d["cyc_total"] for k in d if k.startswith("cyc_") and k not in ("cyc_total", "cyc_max_slot_launch")}
             out["phase_cycles_share"]["max_cycles_one_slot_launch"] = st1["cyc_max_slot_launch"]
             out["phase_cycles_share"]["noise_cycles_per_move"] = d["cyc_noise"] / max(1, d["plies"])
+            out["phase_cycles_share"]["per_level_cycles"] = {k: d["cyc_lvl_" + k] / max(1, d["levels"]) for k in ("wait", "pick", "desc")}
             out["phase_cycles_share"]["total_cycles_per_slot_launch"] = d["cyc_total"] / max(1, d["kernel_launches"]) / args.concurrent
         if not args.no_profile and d["kernel_ms"] > 0:
             achieved = d["traversals"] * bpt / (d["kernel_ms"] * 1e-3) / 1e9

@@ -125,7 +125,7 @@ typedef struct sprl_stats {
     int64_t hbm_bytes;         /* device memory allocated by the engine */
     /* shader-clock cycles summed over game slots, per phase; 0 unless built with -DSPRL_PHASE_TIMERS (diagnosis) */
     int64_t cyc_total, cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise,
-        cyc_max_slot_launch;
+        cyc_max_slot_launch, cyc_lvl_wait, cyc_lvl_pick, cyc_lvl_desc;
 } sprl_stats;
 int sprl_engine_stats(sprl_engine* e, sprl_stats* out);
 

@@ -578,6 +578,9 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
         out->cyc_backup += (int64_t)c.stats.cyc_backup;
         out->cyc_leafio += (int64_t)c.stats.cyc_leafio;
         out->cyc_noise += (int64_t)c.stats.cyc_noise;
+        out->cyc_lvl_wait += (int64_t)c.stats.cyc_lvl_wait;
+        out->cyc_lvl_pick += (int64_t)c.stats.cyc_lvl_pick;
+        out->cyc_lvl_desc += (int64_t)c.stats.cyc_lvl_desc;
         if ((int64_t)c.stats.cyc_max > out->cyc_max_slot_launch) out->cyc_max_slot_launch = (int64_t)c.stats.cyc_max;
         if ((int64_t)c.stats.max_alloc > out->max_nodes_in_arena) out->max_nodes_in_arena = (int64_t)c.stats.max_alloc;
     }

@@ -56,7 +56,7 @@ struct GameStats {
         nodes_created, compactions, games, plies, max_alloc;
     // shader-clock cycles per phase, filled only by the diagnostic build (-DSPRL_PHASE_TIMERS), else 0
     unsigned long long cyc_total, cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio,
-        cyc_noise, cyc_max;
+        cyc_noise, cyc_max, cyc_lvl_wait, cyc_lvl_pick, cyc_lvl_desc;
 };
 
 struct GameCtl {

@@ -80,7 +80,8 @@ struct Game {                 // per-wave working state (wave-uniform values)
     uint32_t d_traversals, d_levels, d_expansions, d_nn_evals, d_terminal, d_gray, d_dup, d_created, d_compactions,
         d_games, d_plies;
 #if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
-    unsigned long long cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise;
+    unsigned long long cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise, cyc_lvl_wait,
+        cyc_lvl_pick, cyc_lvl_desc;
 #endif
 };
 
@@ -420,6 +421,12 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         }
         while (h.exp_epoch == g.epoch && !(h.flags & F_TERMINAL)) {
             uint8_t* np = node_at(g.abase, cur);
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+            const unsigned long long t_l0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostic build: make the memory wait visible
+            const unsigned long long t_l1 = __builtin_amdgcn_s_memtime();
+            g.cyc_lvl_wait += t_l1 - t_l0;
+#endif
             int a;
             if (G::HAS_PASS && G::PASS_EXCLUSIVE && h.legal == 0) {   // pass is the only legal action (mask[64] only)
                 (void)rng_uniform_int(g.rng, 1u);           // bestAction still draws (UCTNode.hpp:250)
@@ -452,6 +459,10 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
                 a = wv::nth_set_bit(ties, r);
             }
             g.d_levels++;
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+            const unsigned long long t_l2 = __builtin_amdgcn_s_memtime();
+            g.cyc_lvl_pick += t_l2 - t_l1;
+#endif
             if (depth >= P.max_depth) { raise_error(P, g, ERR_MAX_DEPTH); return; }
             if (l == 0) lds_path[depth] = (cur << 8) | (uint32_t)a;
             ++depth;
@@ -500,6 +511,9 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
                 break;
             }
             load_node(node_at(g.abase, cur), h, n, w, p, ch);
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+            g.cyc_lvl_desc += __builtin_amdgcn_s_memtime() - t_l2;
+#endif
             if (G::HIST_CAP > 1 && l == 0) {
                 lds->hist[g.ply + depth][0] = h.p0;
                 lds->hist[g.ply + depth][1] = h.p1;
@@ -777,6 +791,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
     g.d_created = g.d_compactions = g.d_games = g.d_plies = 0;
 #if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
     g.cyc_finish = g.cyc_move = g.cyc_select = g.cyc_create = g.cyc_backup = g.cyc_leafio = g.cyc_noise = 0;
+    g.cyc_lvl_wait = g.cyc_lvl_pick = g.cyc_lvl_desc = 0;
 #endif
     g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * SPRL_NODE_BYTES;
     wv::sync();
@@ -852,6 +867,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
         t.cyc_finish += g.cyc_finish; t.cyc_move += g.cyc_move; t.cyc_select += g.cyc_select;
         t.cyc_create += g.cyc_create; t.cyc_backup += g.cyc_backup; t.cyc_leafio += g.cyc_leafio;
         t.cyc_noise += g.cyc_noise;
+        t.cyc_lvl_wait += g.cyc_lvl_wait; t.cyc_lvl_pick += g.cyc_lvl_pick; t.cyc_lvl_desc += g.cyc_lvl_desc;
 #endif
     }
     P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
