@@ -235,7 +235,7 @@ def main():
             "search_shape": shape,
             "rank0": {"kernel_ms": d["kernel_ms"], "nn_ms": d["nn_ms"], "kernel_launches": d["kernel_launches"],
                       "rounds": d["rounds"], "nn_batches": d["nn_batches"], "nn_rows": d["nn_rows"],
-                      "nn_fill": d["nn_evals"] / max(1, d["nn_rows"]), "hbm_gib": st1["hbm_bytes"] / 2**30, "model_load_and_warmup_s": t_load,
+                      "nn_fill": (d["nn_evals"] / d["nn_rows"]) if d["nn_rows"] else None, "hbm_gib": st1["hbm_bytes"] / 2**30, "model_load_and_warmup_s": t_load,
                       "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"]},
         }
         if d.get("cyc_total", 0) > 0:
