@@ -1,0 +1,156 @@
+"""Trainer step on the GPU — SURVEY §8(f) rank 2, the consumer side of the self-play records.
+
+Mirrors `train_network` and the replay window of the reference controller
+(scripts/othello_controller.py:128-241 and :292-343): recency-weighted cross-entropy on the tempered visit
+distributions + recency-weighted MSE on the outcomes, AdamW, 90/10 split, best-validation snapshot, the
+"stop unless the best epoch is recent" rule, LR decay at milestone iterations, last-N-iterations window with linear
+weights.  MI355X-first differences: the window lives in HBM as tensors (no DataLoader, batches are index gathers
+on the device), the best model is kept as an in-memory state_dict and exported once, and with
+torch.distributed initialised (backend "nccl" = RCCL) every rank trains on the samples of its own game shard with
+gradient all-reduce (DistributedDataParallel) — the reference's `prototype/ddp.py` ambition.
+"""
+import copy
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from .network import trace_to_file
+
+EPS = 1e-8  # othello_controller.py:150
+
+
+@dataclass
+class TrainerConfig:
+    batch_size: int = 1024                 # othello_controller.py:52-55
+    lr_init: float = 0.01
+    lr_decay_factor: float = 0.1
+    lr_milestone_iters: List[int] = field(default_factory=lambda: [5, 10, 20])
+    max_groups: int = 10                   # :49-50
+    epochs_per_group: int = 10
+    num_past_iters_to_train: int = 10      # :47
+    linear_weighting: bool = True          # :45
+    val_fraction: float = 0.1              # :135-136
+
+
+def weighted_losses(logits, value, target_pdf, target_value, weight):
+    """Policy: sum_i w_i * CE(pdf_i, softmax(logits_i)) / sum w; value: sum_i w_i (z_i - v_i)^2 / sum w
+    (othello_controller.py:160-170), weights = sample timestamps."""
+    p = torch.softmax(logits, dim=1)
+    wsum = torch.sum(weight)
+    policy = torch.sum(-torch.sum(target_pdf * torch.log(p + EPS), dim=1, keepdim=True) * weight) / wsum
+    val = torch.sum((target_value - value) ** 2 * weight) / wsum
+    return policy, val
+
+
+class ReplayWindow:
+    """The last `num_past_iters_to_train` iterations of samples, resident on `device`
+    (othello_controller.py:292-338)."""
+
+    def __init__(self, cfg: TrainerConfig, device):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.items = []          # (states, dists, outcomes[N,1], timestamps[N,1]) per iteration
+
+    def add(self, iteration, states, dists, outcomes):
+        as_t = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(a)).to(self.device, torch.float32)
+        s, d, o = as_t(states), as_t(dists), as_t(outcomes).reshape(-1, 1)
+        stamp = float(iteration + 1) if self.cfg.linear_weighting else 1.0      # :94
+        t = torch.full((s.shape[0], 1), stamp, device=self.device)
+        assert s.shape[0] == d.shape[0] == o.shape[0]
+        self.items.append((s, d, o, t))
+        while len(self.items) > self.cfg.num_past_iters_to_train:
+            self.items.pop(0)
+
+    def training_tensors(self, iteration):
+        s = torch.cat([i[0] for i in self.items])
+        d = torch.cat([i[1] for i in self.items])
+        o = torch.cat([i[2] for i in self.items])
+        t = torch.cat([i[3] for i in self.items])
+        if self.cfg.linear_weighting:
+            t = t - max(0, iteration + 1 - self.cfg.num_past_iters_to_train)    # :338
+        assert torch.min(t) > 0
+        return s, d, o, t
+
+
+def learning_rate_for(cfg: TrainerConfig, iteration: int) -> float:
+    """LR after the decays applied at the start of every milestone iteration up to `iteration` (:305-307)."""
+    lr = cfg.lr_init
+    for m in cfg.lr_milestone_iters:
+        if iteration >= m:
+            lr *= cfg.lr_decay_factor
+    return lr
+
+
+def _evaluate(net, tensors, idx, batch_size):
+    s, d, o, t = tensors
+    pol = val = 0.0
+    n = 0
+    with torch.no_grad():
+        for k in range(0, idx.numel(), batch_size):
+            b = idx[k:k + batch_size]
+            lo, va = net(s[b])
+            p, v = weighted_losses(lo, va, d[b], o[b], t[b])
+            pol += p.item()
+            val += v.item()
+            n += 1
+    return pol / max(1, n), val / max(1, n)
+
+
+def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Optional[torch.Generator] = None,
+                  ddp: bool = False, log=None):
+    """One controller iteration of training.  Returns (best_state_dict, history); `net` itself keeps training weights
+    (the reference traces the best-validation snapshot but carries the live network into the next iteration)."""
+    s, d, o, t = tensors
+    device = s.device
+    net.to(device)
+    n = s.shape[0]
+    perm = torch.randperm(n, device=device, generator=generator)
+    n_train = int((1.0 - cfg.val_fraction) * n)                                  # :135-138
+    train_idx, val_idx = perm[:n_train], perm[n_train:]
+    model = net
+    if ddp:
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            model = DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None)
+    opt = torch.optim.AdamW(model.parameters(), lr=learning_rate)               # :144
+    best_val, best_epoch, best_state = float("inf"), 0, copy.deepcopy(net.state_dict())
+    history = []
+    for group in range(cfg.max_groups):
+        for epoch in range(cfg.epochs_per_group):
+            model.train()
+            order = train_idx[torch.randperm(train_idx.numel(), device=device, generator=generator)]
+            tp = tv = 0.0
+            nb = 0
+            for k in range(0, order.numel(), cfg.batch_size):
+                b = order[k:k + cfg.batch_size]
+                lo, va = model(s[b])
+                pl, vl = weighted_losses(lo, va, d[b], o[b], t[b])
+                opt.zero_grad(set_to_none=True)
+                (pl + vl).backward()
+                opt.step()
+                tp += pl.item()
+                tv += vl.item()
+                nb += 1
+            model.eval()
+            vp, vv = _evaluate(net, tensors, val_idx, cfg.batch_size) if val_idx.numel() else (tp / nb, tv / nb)
+            val_loss = vp + vv
+            e = epoch + group * cfg.epochs_per_group
+            history.append(dict(epoch=e, train_policy=tp / nb, train_value=tv / nb, val_policy=vp, val_value=vv))
+            if val_loss < best_val:                                              # :210-219
+                best_val, best_epoch = val_loss, e
+                best_state = copy.deepcopy(net.state_dict())
+            if log:
+                log(f"epoch {e}: train {tp / nb:.4f}/{tv / nb:.4f} val {vp:.4f}/{vv:.4f}")
+        # keep going only while the best epoch is among the last half group (:231-233)
+        if best_epoch < (group + 1) * cfg.epochs_per_group - cfg.epochs_per_group // 2:
+            break
+    net.eval()
+    return best_state, dict(best_epoch=best_epoch, best_val=best_val, epochs=history)
+
+
+def export_best(net, best_state, game, path):
+    """Trace the best-validation weights to `path` (CPU weights, like othello_controller.py:237-239)."""
+    snap = copy.deepcopy(net).cpu()
+    snap.load_state_dict(best_state)
+    return trace_to_file(snap.eval(), path, game)

@@ -196,3 +196,21 @@ def test_npy_roundtrip(lib, tmp_path):
     for part in ("states", "distributions", "outcomes"):
         assert open(tmp_path / f"run_iteration_0_{part}.npy", "rb").read() == \
             open(tmp_path / f"ora_iteration_0_{part}.npy", "rb").read()
+
+
+def test_in_process_selfplay_training_loop(lib, tmp_path):
+    """engine -> records -> HBM tensors -> AdamW steps on the GPU -> traced model -> set_model,
+    three iterations of Connect Four in one process, no file polling."""
+    import torch
+    from sprl_amd import trainer as T
+    from sprl_amd.pipeline import LoopConfig, SelfPlayTrainLoop
+    cfg = LoopConfig(game="connect_four", num_iters=3, init_games=64, init_traversals=64, init_max_batch=8,
+                     init_max_queue=4, games=64, traversals=48, num_blocks=1, num_channels=16, root=str(tmp_path),
+                     run_name="gpu_loop")
+    tcfg = T.TrainerConfig(batch_size=256, max_groups=1, epochs_per_group=3)
+    loop = SelfPlayTrainLoop(cfg, tcfg, lib=lib, log=lambda *_: None)
+    hist = loop.run()
+    assert len(hist) == 3 and all(h["games"] == 64 for h in hist)
+    assert str(loop.window.training_tensors(2)[0].device).startswith("cuda")
+    assert hist[2]["best_val"] < hist[0]["best_val"] + 1.0          # training ran and produced finite losses
+    assert all(np.isfinite(h["best_val"]) for h in hist)

@@ -1,0 +1,92 @@
+"""SURVEY §8(f) ranks 1-2 on the CPU: the trainer step's loss/weighting semantics against a literal restatement of
+the reference formula, the replay-window weights, and the in-process self-play -> train -> hot-swap loop (engine
+on the SIMT emulator, network forward as a host callback)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from sprl_amd import engine as E
+from sprl_amd import trainer as T
+from sprl_amd.network import GridResNet
+from sprl_amd.pipeline import LoopConfig, SelfPlayTrainLoop
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+def test_weighted_losses_match_reference_formula():
+    torch.manual_seed(0)
+    lo, va = torch.randn(7, 5), torch.tanh(torch.randn(7, 1))
+    pdf = torch.softmax(torch.randn(7, 5), 1)
+    z = torch.sign(torch.randn(7, 1))
+    w = torch.tensor([1., 1, 2, 2, 3, 3, 3]).reshape(-1, 1)
+    p, v = T.weighted_losses(lo, va, pdf, z, w)
+    sm = torch.softmax(lo, dim=1)                              # othello_controller.py:160-170, literally
+    ref_p = torch.sum(-torch.sum(pdf * torch.log(sm + 1e-8), dim=1, keepdim=True) * w) / torch.sum(w)
+    ref_v = torch.sum((z - va) ** 2 * w) / torch.sum(w)
+    assert torch.equal(p, ref_p) and torch.equal(v, ref_v)
+
+
+def test_replay_window_and_lr_schedule():
+    cfg = T.TrainerConfig(num_past_iters_to_train=3)
+    win = T.ReplayWindow(cfg, "cpu")
+    for it in range(5):
+        win.add(it, np.zeros((2, 3, 6, 7), np.float32), np.full((2, 7), 1 / 7, np.float32), np.ones(2, np.float32))
+    s, d, o, t = win.training_tensors(4)
+    assert s.shape[0] == 6 and o.shape == (6, 1)
+    assert t.reshape(-1).tolist() == [1, 1, 2, 2, 3, 3]        # iterations 2,3,4 -> timestamps 3,4,5 minus (5 - 3)
+    assert [T.learning_rate_for(T.TrainerConfig(), i) for i in (0, 4, 5, 10, 20)] == \
+        pytest.approx([0.01, 0.01, 0.001, 0.0001, 0.00001])
+
+
+def test_training_reduces_loss_and_returns_best_snapshot():
+    torch.manual_seed(1)
+    net = GridResNet(6, 7, 7, 1, 1, 8)
+    n = 256
+    s = (torch.rand(n, 3, 6, 7) > 0.5).float()
+    d = torch.zeros(n, 7)
+    d[torch.arange(n), s[:, 0, 5].argmax(1)] = 1.0             # learnable target: a function of the bottom row
+    o = torch.where(s[:, 2, 0, 0:1] > 0, 1.0, -1.0)
+    t = torch.ones(n, 1)
+    cfg = T.TrainerConfig(batch_size=64, max_groups=2, epochs_per_group=4)
+    best, hist = T.train_network(net, 0.01, (s, d, o, t), cfg, generator=torch.Generator().manual_seed(0))
+    first, last = hist["epochs"][0], hist["epochs"][-1]
+    assert last["train_policy"] < first["train_policy"]
+    assert set(best.keys()) == set(net.state_dict().keys())
+    assert hist["best_val"] <= min(e["val_policy"] + e["val_value"] for e in hist["epochs"]) + 1e-9
+
+
+def test_in_process_loop_hot_swaps_the_model(tmp_path):
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    emu = E.load_library(os.path.join(EMU_DIR, "libsprl_emu.so"))
+    calls = {"n": 0}
+
+    def forward_factory(net):
+        def fwd(planes_ptr, batch, logits_ptr, value_ptr):
+            x = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_float)), shape=(batch, 3, 6, 7))
+            with torch.no_grad():
+                lo, va = net.cpu().eval()(torch.from_numpy(x.copy()))
+            np.ctypeslib.as_array(C.cast(logits_ptr, C.POINTER(C.c_float)), shape=(batch, 7))[:] = lo.numpy()
+            np.ctypeslib.as_array(C.cast(value_ptr, C.POINTER(C.c_float)), shape=(batch,))[:] = va.numpy().reshape(-1)
+            calls["n"] += 1
+            return 0
+        return fwd
+
+    cfg = LoopConfig(game="connect_four", num_iters=2, init_games=4, init_traversals=16, init_max_batch=8,
+                     init_max_queue=4, games=3, traversals=12, num_blocks=1, num_channels=8, root=str(tmp_path),
+                     run_name="loop", write_files=True)
+    tcfg = T.TrainerConfig(batch_size=32, max_groups=1, epochs_per_group=2)
+    loop = SelfPlayTrainLoop(cfg, tcfg, lib=emu, forward_factory=forward_factory, train_device="cpu", log=lambda *_: None)
+    hist = loop.run()
+    assert [h["iteration"] for h in hist] == [0, 1] and hist[0]["games"] == 4 and hist[1]["games"] == 3
+    assert calls["n"] > 0                                      # iteration 1 searched with the freshly trained network
+    for it in (0, 1):
+        assert os.path.exists(tmp_path / "data" / "models" / "loop" / f"traced_loop_iteration_{it}.pt")
+        s = np.load(tmp_path / "data" / "games" / "loop" / "0" / "0" / f"loop_iteration_{it}_states.npy")
+        assert s.shape[0] == hist[it]["samples"]
+    m = torch.jit.load(str(tmp_path / "data" / "models" / "loop" / "traced_loop_iteration_1.pt"))
+    lo, va = m(torch.zeros(2, 3, 6, 7))
+    assert lo.shape == (2, 7) and va.shape == (2, 1)
