@@ -90,3 +90,21 @@ def test_in_process_loop_hot_swaps_the_model(tmp_path):
     m = torch.jit.load(str(tmp_path / "data" / "models" / "loop" / "traced_loop_iteration_1.pt"))
     lo, va = m(torch.zeros(2, 3, 6, 7))
     assert lo.shape == (2, 7) and va.shape == (2, 1)
+
+
+@pytest.mark.parametrize("game", ["c4", "othello", "go"])
+def test_compact_record_format_v2_roundtrip(game, tmp_path):
+    """the compact on-disk form expands to exactly the reference arrays."""
+    from sprl_amd import records_v2
+    import parity
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    emu = E.load_library(os.path.join(EMU_DIR, "libsprl_emu.so"))
+    _, rec, _ = parity.run_engine(emu, game, 2, concurrent_games=2, num_traversals=20, seed=13)
+    path = str(tmp_path / "run_iteration_0.sprl2")
+    records_v2.write_compact(path, rec)
+    s2, d2, o2 = records_v2.load_compact(path)
+    s1, d1, o1 = rec.expand()
+    assert s1.shape == s2.shape and (s1 == s2).all()
+    assert (d1.view(np.uint32) == d2.view(np.uint32)).all() and (o1 == o2).all()
+    v1_bytes = s1.nbytes + d1.nbytes + o1.nbytes
+    assert os.path.getsize(path) * 8 < v1_bytes
