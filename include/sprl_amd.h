@@ -91,6 +91,24 @@ int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len);
 typedef int (*sprl_forward_fn)(void* user, const float* planes, int32_t batch, float* logits, float* value);
 int sprl_engine_set_forward(sprl_engine* e, sprl_forward_fn fn, void* user);
 
+/* Match play between two agents — the data-parallel form of cpp/src/Evaluate.cpp:37-170 (two UCTTrees per game,
+ * agents/UCTNetworkAgent.hpp:45-108, interface/play.hpp:22-60).  Game i seeds Random(seed, stream_base + i); agent k
+ * moves first in the games with i % 2 == k (Evaluate.cpp:126-130).  Tree options as in Evaluate.cpp:94-112: the
+ * caller passes dir_eps 0.25 / dir_alpha 0.1 / add_noise 1 / u_weight in `cfg`; per agent: symmetrisation and
+ * InitQ.  `cfg->concurrent_games` game PAIRS of trees are resident at once.  Othello, Connect Four, Go 7x7.
+ * Outputs (host memory, caller-owned): winners[num_games] (0, 1, -1 = draw; colour, not agent),
+ * nplies[num_games], actions[num_games][max_plies] (-1 padded). */
+enum { SPRL_INITQ_PARENT = 0, SPRL_INITQ_ZERO = 1 };
+typedef struct sprl_match_agent {
+    const char* model;          /* "random", "heuristic" (Othello) or a traced model file; unused when forward != NULL */
+    sprl_forward_fn forward;    /* optional forward hook (device pointers), as sprl_engine_set_forward */
+    void* forward_user;
+    int32_t use_symmetry;       /* Evaluate.cpp:49,51 */
+    int32_t init_q;             /* Evaluate.cpp:50,52: useParentQ -> SPRL_INITQ_PARENT, else SPRL_INITQ_ZERO */
+} sprl_match_agent;
+int sprl_match_play(const sprl_config* cfg, const sprl_match_agent* agent0, const sprl_match_agent* agent1,
+                    int32_t num_games, int8_t* winners, int32_t* nplies, int16_t* actions, int32_t max_plies);
+
 /* Compact self-play records of a run, host memory owned by the library until sprl_records_free.
  * Sample order = the reference's: game-major, ply-major (SelfPlay.hpp:86-92,127-133,154-163).  */
 typedef struct sprl_records {

@@ -25,7 +25,7 @@ class Config(C.Structure):
         ("dir_eps", C.c_float), ("dir_alpha", C.c_float), ("u_weight", C.c_float),
         ("early_cutoff", C.c_int32), ("early_exp", C.c_float), ("rest_exp", C.c_float),
         ("use_sym", C.c_int32), ("add_noise", C.c_int32), ("eval_kind", C.c_int32), ("math_mode", C.c_int32),
-        ("mask_frame", C.c_int32), ("pad_", C.c_int32),
+        ("mask_frame", C.c_int32), ("init_q", C.c_int32),
         ("forward", FORWARD_FN), ("forward_user", C.c_void_p),
     ]
 
@@ -75,6 +75,7 @@ def lib():
         L.orc_search_trace.argtypes = [C.POINTER(Config), C.c_int, C.c_uint64, C.c_int] + [C.c_void_p] * 3
         L.orc_selfplay.argtypes = [C.POINTER(Config), C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int] + \
             [C.c_void_p] * 6 + [C.POINTER(Stats)]
+        L.orc_match.argtypes = [C.POINTER(Config), C.POINTER(Config), C.c_int, C.c_uint64, C.c_int] + [C.c_void_p] * 3 + [C.c_int]
         L.orc_write_npy_f32.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_write_records.argtypes = [C.POINTER(Config), C.c_char_p, C.c_int] + [C.c_void_p] * 5
         _lib = L
@@ -103,7 +104,7 @@ DEFAULTS = {
 
 def make_config(game, num_traversals, *, max_batch=None, max_queue=None, dir_eps=None, dir_alpha=None,
                 u_weight=1.1, early_cutoff=15, early_exp=0.98, rest_exp=10.0, use_sym=1, add_noise=1,
-                eval_kind=EVAL_RANDOM, math_mode=MATH_LIBM, mask_frame=MASK_REFERENCE, forward=None):
+                eval_kind=EVAL_RANDOM, math_mode=MATH_LIBM, mask_frame=MASK_REFERENCE, forward=None, init_q=0):
     d = DEFAULTS[game]
     cfg = Config()
     cfg.game = game
@@ -121,6 +122,7 @@ def make_config(game, num_traversals, *, max_batch=None, max_queue=None, dir_eps
     cfg.eval_kind = eval_kind
     cfg.math_mode = math_mode
     cfg.mask_frame = mask_frame
+    cfg.init_q = init_q
     if forward is not None:
         cfg.forward = forward
     return cfg
@@ -192,6 +194,24 @@ def step(game, board, player, mask, action):
     return nb, nm, t.value, w.value
 
 
+def replay_winner(game, actions):
+    """Replay a move list from the start position with the oracle's rules (Othello / Connect Four: no history needed).
+    Every move must be legal and the list must end exactly at a terminal position; returns the winner colour (-1 = draw)."""
+    g = GEOM[game]
+    board = np.zeros(g["cells"], np.int8)
+    mask = np.zeros(g["A"], np.float32)
+    pl = C.c_int()
+    lib().orc_start(game, vp(board), C.byref(pl), vp(mask))
+    player, term, win = pl.value, 0, -1
+    for a in actions:
+        assert not term, "moves after the end of the game"
+        assert mask[int(a)] > 0, f"illegal move {int(a)}"
+        board, mask, term, win = step(game, board, player, mask, int(a))
+        player = 1 - player
+    assert term, "the move list stops before the game ends"
+    return win
+
+
 def symmetrize(game, board, dist):
     g = GEOM[game]
     board = np.ascontiguousarray(board, np.int8)
@@ -227,3 +247,13 @@ def rng_stream(seed, stream, n):
 def write_records(cfg, prefix, res):
     return lib().orc_write_records(C.byref(cfg), prefix.encode(), len(res["players"]), vp(res["boards"]),
                                    vp(res["players"]), vp(res["sizes"]), vp(res["dists"]), vp(res["outcomes"]))
+
+
+def match(cfg0, cfg1, num_games, seed, stream_base=1, max_plies=256):
+    """Net-vs-net games (Evaluate.cpp): returns winners[int8], actions[num_games, max_plies], nplies."""
+    winners = np.zeros(num_games, np.int8)
+    actions = np.full((num_games, max_plies), -1, np.int16)
+    nplies = np.zeros(num_games, np.int32)
+    lib().orc_match(C.byref(cfg0), C.byref(cfg1), num_games, seed, stream_base, vp(winners), vp(actions), vp(nplies),
+                    max_plies)
+    return winners, actions, nplies

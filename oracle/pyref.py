@@ -50,6 +50,8 @@ def lib(torch=False):
         L.ref_go_search_trace.argtypes = [C.c_int] * 5 + [C.c_float] * 2 + [C.c_int] * 2 + [C.c_uint64, C.c_int] + \
             [C.c_void_p] * 3
         L.ref_go_komi.restype = C.c_float
+        for g in ("othello", "c4"):
+            getattr(L, f"ref_{g}_match").argtypes = [C.c_int] * 10 + [C.c_uint64, C.c_int] + [C.c_void_p] * 3 + [C.c_int]
         L.ref_othello_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         L.ref_othello_evaluate.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5
         L.ref_c4_known_answer.argtypes = [C.c_void_p]
@@ -149,3 +151,16 @@ def othello_evaluate(kind, boards, players, masks, model_path=None):
         lib(True).ref_torch_othello_evaluate(model_path.encode(), n, vp(boards), vp(players), vp(masks), vp(pol),
                                              vp(val))
     return pol, val
+
+
+def match(game, kind0, kind1, num_games, traversals, max_batch, max_queue, sym0, pq0, sym1, pq1, seed, stream_base=1,
+          max_plies=256):
+    """Evaluate.cpp-style matches through the reference's UCTNetworkAgent + playGame."""
+    winners = np.zeros(num_games, np.int8)
+    actions = np.full((num_games, max_plies), -1, np.int16)
+    nplies = np.zeros(num_games, np.int32)
+    rc = getattr(lib(), f"ref_{game}_match")(kind0, kind1, num_games, traversals, max_batch, max_queue, sym0, pq0, sym1,
+                                            pq1, seed, stream_base, vp(winners), vp(actions), vp(nplies), max_plies)
+    if rc != 0:
+        raise RuntimeError("reference match: replay disagreed with playGame")
+    return winners, actions, nplies

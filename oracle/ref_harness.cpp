@@ -25,6 +25,8 @@
 #include "symmetry/ConnectFourSymmetrizer.hpp"
 #include "selfplay/SelfPlay.hpp"
 #include "uct/UCTTree.hpp"
+#include "agents/UCTNetworkAgent.hpp"
+#include "evaluate/play.hpp"
 #include "utils/random.hpp"
 #include "utils/npy.hpp"
 
@@ -205,6 +207,57 @@ int searchTrace(int evalKind, int moves, int numTraversals, int maxBatch, int ma
     return m;
 }
 
+// Net-vs-net matches exactly as Evaluate.cpp:88-154 sets them up (trees with eps 0.25 / alpha 0.1 / noise on,
+// InitQ per agent, optional symmetrizer, UCTNetworkAgent, colours alternating with the game index), driven by the
+// reference's playGame (evaluate/play.hpp:24-70).  Each game is replayed once more with the same seed through the
+// same agent calls to record the action sequence; the two runs must agree on the winner.
+template <typename T>
+int playMatches(int kind0, int kind1, int numGames, int numTraversals, int maxBatch, int maxQueue,
+                int useSym0, int parentQ0, int useSym1, int parentQ1, uint64_t seed, int streamBase,
+                int8_t* winners, int16_t* actions, int32_t* nplies, int maxPlies) {
+    typename T::Sym sym;
+    auto* net0 = makeEvaluator<T>(kind0);
+    auto* net1 = makeEvaluator<T>(kind1);
+    using Tree = UCTTree<typename T::Node, typename T::State, T::A>;
+    using Agent = UCTNetworkAgent<typename T::Node, typename T::State, T::A>;
+    for (int t = 0; t < numGames; ++t) {
+        Player winnerRef = Player::NONE;
+        for (int pass = 0; pass < 2; ++pass) {
+            reseed(seed, streamBase + t);
+            Tree tree0 { std::make_unique<typename T::Node>(), 0.25, 0.1, parentQ0 ? InitQ::PARENT : InitQ::ZERO,
+                         useSym0 ? &sym : nullptr, true };
+            Tree tree1 { std::make_unique<typename T::Node>(), 0.25, 0.1, parentQ1 ? InitQ::PARENT : InitQ::ZERO,
+                         useSym1 ? &sym : nullptr, true };
+            Agent a0 { net0, &tree0, numTraversals, maxBatch, maxQueue };
+            Agent a1 { net1, &tree1, numTraversals, maxBatch, maxQueue };
+            std::array<IAgent<typename T::Node, typename T::State, T::A>*, 2> agents;
+            if (t % 2 == 0) agents = { &a0, &a1 };
+            else agents = { &a1, &a0 };
+            typename T::Node rootNode {};
+            if (pass == 0) {
+                winnerRef = playGame<typename T::Node, typename T::State, T::A>(&rootNode, agents, false);
+            } else {
+                GameNode<typename T::Node, typename T::State, T::A>* cur = &rootNode;
+                int ply = 0;
+                while (!cur->isTerminal()) {
+                    int pi = static_cast<int>(cur->getPlayer());
+                    ActionIdx a = agents[pi]->act(cur, false);
+                    agents[1 - pi]->opponentAct(a);
+                    if (ply < maxPlies) actions[t * maxPlies + ply] = a;
+                    ++ply;
+                    cur = cur->getAddChild(a);
+                }
+                if (cur->getWinner() != winnerRef) return -1;
+                nplies[t] = ply;
+                winners[t] = static_cast<int8_t>(cur->getWinner());
+            }
+        }
+    }
+    delete net0;
+    delete net1;
+    return 0;
+}
+
 template <typename T>
 void symmetrize(const int8_t* board, int player, const float* dist, int nsym,
                 int8_t* boardsOut, float* distsOut, int8_t* inverseOut) {
@@ -363,6 +416,18 @@ int ref_go_search_trace(int evalKind, int moves, int numTraversals, int maxBatch
                         float* stats, int32_t* trav, int16_t* chosen) {
     return searchTrace<GoTraits>(evalKind, moves, numTraversals, maxBatch, maxQueue, eps, alpha, useSym, addNoise,
                                  seed, stream, stats, trav, chosen);
+}
+int ref_othello_match(int kind0, int kind1, int numGames, int numTraversals, int maxBatch, int maxQueue,
+                      int useSym0, int parentQ0, int useSym1, int parentQ1, uint64_t seed, int streamBase,
+                      int8_t* winners, int16_t* actions, int32_t* nplies, int maxPlies) {
+    return playMatches<OthTraits>(kind0, kind1, numGames, numTraversals, maxBatch, maxQueue, useSym0, parentQ0, useSym1,
+                                  parentQ1, seed, streamBase, winners, actions, nplies, maxPlies);
+}
+int ref_c4_match(int kind0, int kind1, int numGames, int numTraversals, int maxBatch, int maxQueue,
+                 int useSym0, int parentQ0, int useSym1, int parentQ1, uint64_t seed, int streamBase,
+                 int8_t* winners, int16_t* actions, int32_t* nplies, int maxPlies) {
+    return playMatches<C4Traits>(kind0, kind1, numGames, numTraversals, maxBatch, maxQueue, useSym0, parentQ0, useSym1,
+                                 parentQ1, seed, streamBase, winners, actions, nplies, maxPlies);
 }
 int ref_go_board_width() { return GO_BOARD_WIDTH; }
 float ref_go_komi() { return GO_KOMI; }

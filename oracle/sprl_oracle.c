@@ -808,7 +808,7 @@ static int best_action(tree* t, node* n) {                                   /* 
 static node* get_add_child(tree* t, node* n, int action) {                   /* UCTNode.hpp:258-284 */
     if (!n->children[action]) {
         n->children[action] = node_new(t, n, action);
-        n->W[action] = n->evaluated ? n->net_value : 0.0f;                   /* InitQ::PARENT */
+        n->W[action] = (t->cfg->init_q == 0 && n->evaluated) ? n->net_value : 0.0f;   /* InitQ::PARENT / ZERO */
     }
     return n->children[action];
 }
@@ -1017,6 +1017,37 @@ int orc_search_trace(const orc_config* cfg, int moves, uint64_t seed, int stream
     }
     node_free(t.root, A);
     return m;
+}
+
+int orc_match(const orc_config* cfg0, const orc_config* cfg1, int num_games, uint64_t seed, int stream_base,
+              int8_t* winners, int16_t* actions, int32_t* nplies, int max_plies) {
+    for (int g = 0; g < num_games; ++g) {
+        orc_rng rng;
+        orc_rng_seed(&rng, seed, stream_base + g);
+        tree t0, t1;
+        tree_init(&t0, cfg0, &rng, NULL);
+        tree_init(&t1, cfg1, &rng, NULL);
+        tree* agents[2];                                                     /* Evaluate.cpp:126-130 */
+        agents[0] = (g % 2 == 0) ? &t0 : &t1;
+        agents[1] = (g % 2 == 0) ? &t1 : &t0;
+        int A = t0.g.A, ply = 0;
+        while (!t0.decision->terminal) {                                     /* play.hpp:34-52 */
+            tree* mover = agents[t0.decision->player];
+            search_move(mover);                                              /* UCTNetworkAgent.hpp:45-58 */
+            int best = 0;                                                    /* std::max_element: first maximum (:88-89) */
+            for (int a = 1; a < A; ++a)
+                if (mover->decision->N[a] > mover->decision->N[best]) best = a;
+            advance_decision(&t0, best);                                     /* act: :101 / opponentAct: :106-108 */
+            advance_decision(&t1, best);
+            if (ply < max_plies) actions[(size_t)g * max_plies + ply] = (int16_t)best;
+            ++ply;
+        }
+        nplies[g] = ply;
+        winners[g] = (int8_t)t0.decision->winner;
+        node_free(t0.root, A);
+        node_free(t1.root, A);
+    }
+    return 0;
 }
 
 /* One game of self-play — selfplay/SelfPlay.hpp:51-192.  Returns number of samples appended, -1 on overflow. */

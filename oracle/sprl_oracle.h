@@ -54,7 +54,7 @@ typedef struct {
     int32_t eval_kind;       /* ORC_EVAL_* */
     int32_t math_mode;       /* ORC_MATH_* */
     int32_t mask_frame;      /* ORC_MASK_* (Q1; reference = original-frame mask on symmetrised policy) */
-    int32_t pad_;
+    int32_t init_q;          /* 0 = InitQ::PARENT (workers), 1 = InitQ::ZERO (UCTNode.hpp:24-28,267-273) */
     orc_forward_fn forward;  /* ORC_EVAL_CALLBACK */
     void* forward_user;
 } orc_config;
@@ -111,6 +111,12 @@ int orc_search_trace(const orc_config* cfg, int moves, uint64_t seed, int stream
 int orc_selfplay(const orc_config* cfg, int num_games, uint64_t seed, int stream_base, int per_game_stream,
                  int cap, int8_t* boards, int8_t* players, int8_t* sizes, float* dists, float* outcomes,
                  int32_t* game_offsets, orc_stats* stats);
+
+/* net-vs-net matches: Evaluate.cpp:88-154 + evaluate/play.hpp:24-70 + agents/UCTNetworkAgent.hpp:42-108.
+ * cfg0 / cfg1 describe agent 0 / agent 1 (evaluator, symmetrizer, init_q, budgets); agent (t % 2) plays Player ZERO
+ * in game t; both trees share one RNG stream (seed, stream_base + t).  actions: [num_games][max_plies]. */
+int orc_match(const orc_config* cfg0, const orc_config* cfg1, int num_games, uint64_t seed, int stream_base,
+              int8_t* winners, int16_t* actions, int32_t* nplies, int max_plies);
 
 /* records: plane encoding (GridWorker.hpp:146-171) + .npy v1.0 writer (utils/npy.hpp:430-476) */
 int orc_write_npy_f32(const char* path, const float* data, int ndim, const uint64_t* shape);

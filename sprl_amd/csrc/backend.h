@@ -21,6 +21,8 @@ int dmemset(void* dst, int v, size_t n);
 int sync();
 // one 64-lane wavefront per game slot, on the null stream
 int launch_step(int game, const EngineParams& P);
+// match play: slots (pair, pair + num_slots/2) hold the two agents' trees of one game; Othello, Connect Four, Go 7x7
+int launch_match(int game, const EngineParams& P);
 // leaf_count -> leaf_offset (exclusive scan, slot order) + counters->leaf_total, then gather the queued leaves'
 // planes from the sparse staging into the dense network batch
 int launch_compact(const EngineParams& P, int floats_per_leaf);

@@ -28,6 +28,13 @@ __global__ void __launch_bounds__(64) step_kernel(EngineParams P) {
 }
 
 template <class G>
+__global__ void __launch_bounds__(64) match_kernel(EngineParams P) {
+    __shared__ sprl::WaveLds<G> lds;
+    const int slot = (int)blockIdx.x;
+    if (slot < P.num_slots) sprl::step_match<G>(P, slot, &lds);
+}
+
+template <class G>
 __global__ void __launch_bounds__(64) step_kernel_wide(EngineParams P) {
     __shared__ sprlw::WaveLdsW<G> lds;
     const int slot = (int)blockIdx.x;
@@ -138,6 +145,18 @@ int launch_step(int game, const EngineParams& P) {
     else if (game == SPRL_GAME_GO7W) hipLaunchKernelGGL(step_kernel_wide<GoN<7>>, grid, block, 0, 0, P);
     else hipLaunchKernelGGL(step_kernel<ConnectFour>, grid, block, 0, 0, P);
     return ok(hipGetLastError(), "step_kernel launch") ? 0 : -1;
+}
+
+int launch_match(int game, const EngineParams& P) {
+    dim3 grid((unsigned)P.num_slots), block(64);
+    if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(match_kernel<Othello>, grid, block, 0, 0, P);
+    else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(match_kernel<Go7>, grid, block, 0, 0, P);
+    else if (game == SPRL_GAME_CONNECT_FOUR) hipLaunchKernelGGL(match_kernel<ConnectFour>, grid, block, 0, 0, P);
+    else {
+        g_err = "match play is built for Othello, Connect Four and Go 7x7";
+        return -1;
+    }
+    return ok(hipGetLastError(), "match_kernel launch") ? 0 : -1;
 }
 
 int launch_compact(const EngineParams& P, int floats_per_leaf) {

@@ -157,6 +157,32 @@ int load_torch_plugin(sprl_engine* e) {
     return 0;
 }
 
+// Load a traced model through the LibTorch plugin and touch every batch shape the round loop can produce (multiples
+// of the bucket) once, so that the convolution library's per-shape solver selection happens here and not inside a run.
+int load_network(sprl_engine* e, const char* model, void** out) {
+    int rc = load_torch_plugin(e);
+    if (rc) return rc;
+    char err[512] = { 0 };
+    void* m = e->torch.load(model, e->cfg.device, err, (int)sizeof(err));
+    if (!m) return fail(SPRL_E_MODEL, std::string("cannot load TorchScript model '") + model + "': " + err);
+    const int max_rows = e->P.num_slots * e->P.max_queue;
+    int last = 0;
+    for (int rows = e->nn_bucket;; rows += e->nn_bucket) {
+        int b = rows < max_rows ? rows : max_rows;
+        if (b == last) break;
+        last = b;
+        if (e->torch.forward(m, e->P.nn_dense, b, e->g.planes, e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, err,
+                             (int)sizeof(err)) != 0) {
+            e->torch.release(m);
+            return fail(SPRL_E_MODEL, std::string("network warm-up forward failed: ") + err);
+        }
+        if (b == max_rows) break;
+    }
+    be::sync();
+    *out = m;
+    return 0;
+}
+
 int check_device_error(sprl_engine* e, const Counters& c) {
     if (c.error == ERR_NONE) return 0;
     char buf[256];
@@ -305,29 +331,13 @@ int sprl_engine_set_model(sprl_engine* e, const char* model) {
         e->eval_kind = SPRL_EVAL_HEURISTIC;
         return 0;
     }
-    int rc = load_torch_plugin(e);
+    void* m = nullptr;
+    int rc = load_network(e, model, &m);
     if (rc) return rc;
-    char err[512] = { 0 };
-    void* m = e->torch.load(model, e->cfg.device, err, (int)sizeof(err));
-    if (!m) return fail(SPRL_E_MODEL, std::string("cannot load TorchScript model '") + model + "': " + err);
     if (e->torch_model) e->torch.release(e->torch_model);
     e->torch_model = m;
     e->forward_cb = nullptr;
     e->eval_kind = SPRL_EVAL_NETWORK;
-    // Touch every batch shape the round loop can produce (multiples of the bucket) once, so that the convolution
-    // library's per-shape solver selection happens here and not inside a self-play run.
-    const int max_rows = e->P.num_slots * e->P.max_queue;
-    int last = 0;
-    for (int rows = e->nn_bucket;; rows += e->nn_bucket) {
-        int b = rows < max_rows ? rows : max_rows;
-        if (b == last) break;
-        last = b;
-        if (e->torch.forward(m, e->P.nn_dense, b, e->g.planes, e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, err,
-                             (int)sizeof(err)) != 0)
-            return fail(SPRL_E_MODEL, std::string("network warm-up forward failed: ") + err);
-        if (b == max_rows) break;
-    }
-    be::sync();
     return 0;
 }
 
@@ -543,6 +553,132 @@ int sprl_engine_run(sprl_engine* e, int32_t num_games, sprl_records* out) {
         if (rc) return rc;
     } while (done < num_games);
     return sprl_engine_collect(e, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// match play
+// ---------------------------------------------------------------------------------------------------
+int sprl_match_play(const sprl_config* cfg, const sprl_match_agent* agent0, const sprl_match_agent* agent1,
+                    int32_t num_games, int8_t* winners, int32_t* nplies, int16_t* actions, int32_t max_plies) {
+    if (!cfg || !agent0 || !agent1 || !winners || !nplies) return fail(SPRL_E_CONFIG, "null argument");
+    if (num_games < 1) return fail(SPRL_E_CONFIG, "num_games must be >= 1");
+    if (actions && max_plies < 1) return fail(SPRL_E_CONFIG, "max_plies must be >= 1 when actions are requested");
+    if (cfg->game != SPRL_OTHELLO && cfg->game != SPRL_CONNECT_FOUR && cfg->game != SPRL_GO7)
+        return fail(SPRL_E_CONFIG, "match play is built for Othello, Connect Four and Go 7x7");
+    sprl_config c = *cfg;
+    const int pairs = c.concurrent_games < num_games ? c.concurrent_games : num_games;
+    if (pairs < 1) return fail(SPRL_E_CONFIG, "concurrent_games must be >= 1");
+    c.concurrent_games = 2 * pairs;                  // slot p: agent 0's tree, slot pairs + p: agent 1's tree
+    if (actions) c.max_plies = max_plies;
+    sprl_engine* e = nullptr;
+    int rc = sprl_engine_create(&c, &e);
+    if (rc) return rc;
+    EngineParams& P = e->P;
+    const sprl_match_agent* ag[2] = { agent0, agent1 };
+    void* models[2] = { nullptr, nullptr };
+    auto done = [&](int code) {
+        for (void* m : models)
+            if (m) e->torch.release(m);
+        sprl_engine_destroy(e);
+        return code;
+    };
+    bool any_net = false;
+    for (int k = 0; k < 2; ++k) {
+        P.m_use_sym[k] = ag[k]->use_symmetry ? 1 : 0;
+        P.m_init_q_zero[k] = ag[k]->init_q == SPRL_INITQ_ZERO ? 1 : 0;
+        if (ag[k]->forward) {
+            P.m_eval_kind[k] = EVAL_NETWORK;
+        } else if (!ag[k]->model) {
+            return done(fail(SPRL_E_CONFIG, "agent has neither a model nor a forward hook"));
+        } else if (strcmp(ag[k]->model, "random") == 0) {
+            P.m_eval_kind[k] = EVAL_RANDOM;
+        } else if (strcmp(ag[k]->model, "heuristic") == 0) {
+            if (c.game != SPRL_OTHELLO) return done(fail(SPRL_E_CONFIG, "the heuristic evaluator exists for Othello only"));
+            P.m_eval_kind[k] = EVAL_HEURISTIC;
+        } else {
+            if ((rc = load_network(e, ag[k]->model, &models[k])) != 0) return done(rc);
+            P.m_eval_kind[k] = EVAL_NETWORK;
+        }
+        any_net = any_net || P.m_eval_kind[k] == EVAL_NETWORK;
+    }
+    const size_t na = (size_t)num_games * (size_t)P.max_plies;
+    bool ok = true;
+    ok = ok && (P.mailbox = (Mailbox*)dev_alloc(e, (size_t)P.num_slots * sizeof(Mailbox)));
+    ok = ok && (P.match_actions = (int16_t*)dev_alloc(e, na * sizeof(int16_t)));
+    ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
+    ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
+    if (!ok) return done(fail(SPRL_E_DEVICE, std::string("match allocation failed (") + be::last_error() + ")"));
+    P.num_games = num_games;
+    std::vector<GameCtl> ctl((size_t)P.num_slots);
+    memset(ctl.data(), 0, ctl.size() * sizeof(GameCtl));
+    for (int s = 0; s < P.num_slots; ++s) {
+        ctl[(size_t)s].status = ST_FRESH;
+        ctl[(size_t)s].arena = (uint32_t)s;
+    }
+    std::vector<uint32_t> used((size_t)(P.num_slots + P.num_spare), 0u);
+    for (int s = 0; s < P.num_slots; ++s) used[(size_t)s] = 1u;
+    Counters cn;
+    memset(&cn, 0, sizeof(cn));
+    rc = 0;
+    rc |= be::h2d(P.ctl, ctl.data(), ctl.size() * sizeof(GameCtl));
+    rc |= be::h2d(P.arena_used, used.data(), used.size() * sizeof(uint32_t));
+    rc |= be::h2d(P.counters, &cn, sizeof(cn));
+    rc |= be::dmemset(P.mailbox, 0, (size_t)P.num_slots * sizeof(Mailbox));
+    rc |= be::dmemset(P.match_actions, 0xff, na * sizeof(int16_t));
+    rc |= be::dmemset(P.rec_nplies, 0, (size_t)num_games * sizeof(int32_t));
+    rc |= be::sync();
+    if (rc) return done(fail(SPRL_E_DEVICE, be::last_error()));
+
+    const int floats_per_leaf = e->g.planes * e->g.cells;
+    const int max_rows = P.num_slots * P.max_queue;
+    P.rounds = any_net ? 1 : 16;
+    // every launch either advances a search or hands a move over; bound the loop all the same
+    const int64_t launch_cap = (int64_t)((num_games + pairs - 1) / pairs) * (int64_t)e->g.default_max_plies *
+                               ((int64_t)P.num_traversals + 4) + 1024;
+    for (int64_t it = 0;; ++it) {
+        if (it > launch_cap) return done(fail(SPRL_E_STATE, "match did not finish within its launch bound"));
+        P.launch_seq = (uint32_t)(it + 1);
+        be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
+        if (be::launch_match(c.game, P) != 0) return done(fail(SPRL_E_DEVICE, be::last_error()));
+        if (any_net && be::launch_compact(P, floats_per_leaf) != 0) return done(fail(SPRL_E_DEVICE, be::last_error()));
+        if (be::sync() != 0 || be::d2h(&cn, P.counters, sizeof(cn)) != 0) return done(fail(SPRL_E_DEVICE, be::last_error()));
+        if (cn.error != ERR_NONE) return done(check_device_error(e, cn));
+        if (any_net && cn.leaf_total > 0) {
+            // rows [0, split) belong to agent 0's trees, [split, total) to agent 1's: one forward per agent
+            uint32_t split = 0;
+            if (be::d2h(&split, P.leaf_offset + pairs, sizeof(split)) != 0) return done(fail(SPRL_E_DEVICE, be::last_error()));
+            const int lo[2] = { 0, (int)split }, hi[2] = { (int)split, (int)cn.leaf_total };
+            for (int k = 0; k < 2; ++k) {
+                const int rows = hi[k] - lo[k];
+                if (rows <= 0 || P.m_eval_kind[k] != EVAL_NETWORK) continue;
+                int batch = (rows + e->nn_bucket - 1) / e->nn_bucket * e->nn_bucket;   // padding rows land on rows that
+                if (lo[k] + batch > max_rows) batch = max_rows - lo[k];                 // are rewritten or never read
+                const float* in = P.nn_dense + (size_t)lo[k] * (size_t)floats_per_leaf;
+                float* lg = e->nn_logits + (size_t)lo[k] * (size_t)e->g.A;
+                float* va = e->nn_value + lo[k];
+                char err[512] = { 0 };
+                int frc;
+                if (ag[k]->forward) {
+                    frc = ag[k]->forward(ag[k]->forward_user, in, batch, lg, va);
+                    if (frc) snprintf(err, sizeof(err), "forward callback returned %d", frc);
+                } else {
+                    frc = e->torch.forward(models[k], in, batch, e->g.planes, e->g.rows, e->g.cols, lg, e->g.A, va, err, (int)sizeof(err));
+                }
+                if (frc) return done(fail(SPRL_E_MODEL, std::string("network forward failed: ") + err));
+                e->nn_batches++;
+                e->nn_rows += batch;
+            }
+        }
+        e->launches++;
+        if (cn.games_done >= (uint32_t)num_games) break;
+        if (cn.active_slots == 0) return done(fail(SPRL_E_STATE, "match stalled: no active tree but games remain"));
+    }
+    rc = be::sync();
+    rc |= be::d2h(winners, P.rec_winner, (size_t)num_games);
+    rc |= be::d2h(nplies, P.rec_nplies, (size_t)num_games * sizeof(int32_t));
+    if (actions) rc |= be::d2h(actions, P.match_actions, na * sizeof(int16_t));
+    if (rc) return done(fail(SPRL_E_DEVICE, be::last_error()));
+    return done(0);
 }
 
 void sprl_records_free(sprl_records* r) {

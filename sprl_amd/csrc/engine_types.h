@@ -89,6 +89,16 @@ struct Counters {
     uint32_t pad[2];
 };
 
+struct alignas(32) Mailbox {   // match play: the move a side has just made, handed to the partner tree of the same game
+    uint64_t ply_launch;    // low 32: index of the ply that was played, plus one (0 = nothing yet); high 32: sequence number
+                            // of the launch that wrote it.  One 64-bit word: an entry is consumed only by a LATER launch
+                            // (kernel boundary = the only cross-XCD visibility the protocol relies on)
+    uint64_t rng_state;     // the game's RNG stream moves with the turn (one global stream in the reference)
+    uint32_t game;
+    uint32_t action;
+    uint32_t pad[2];
+};
+
 struct EngineParams {
     int32_t num_traversals, max_batch, max_queue;
     float dir_eps, dir_alpha, u_weight;
@@ -99,6 +109,12 @@ struct EngineParams {
     uint64_t seed;
     int32_t node_cap, num_slots, num_spare, num_games, max_plies, rounds;
     int32_t max_depth, planes;
+    int32_t init_q_zero;    // 0 = InitQ::PARENT (workers), 1 = InitQ::ZERO (uct/UCTNode.hpp:24-28,267-273)
+    // match play (Evaluate.cpp): per-agent options, agent = slot & 1, game = slot >> 1
+    int32_t m_use_sym[2], m_eval_kind[2], m_init_q_zero[2];
+    uint32_t launch_seq;
+    Mailbox* mailbox;       // [num_slots]
+    int16_t* match_actions; // [num_games][max_plies]
     uint8_t* arenas;
     uint32_t* arena_used;   // [num_slots + num_spare] 0 free / 1 used
     GameCtl* ctl;

@@ -488,7 +488,7 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
                 make_child<G>(P, g, lds, pos_of<G>(h), a, g.ply + depth, cs);
                 write_new_node<G>(node_at(g.abase, c), cs, a);
                 SPRL_TOC(g.cyc_create, t_cr);
-                w_a = h.value;                              // InitQ::PARENT (UCTNode.hpp:271-273)
+                w_a = P.init_q_zero ? 0.0f : h.value;       // InitQ::PARENT / ZERO (UCTNode.hpp:267-273)
                 g.d_created++;
                 if (G::HAS_PASS && a == PASS_A) hp->passChild = c;
                 else if (l == a) rowC(np)[l] = (uint16_t)c;
@@ -638,10 +638,7 @@ SPRL_DEV_NOINLINE bool compact_arena(const EngineParams& P, Game& g) {
 // new game / move
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV_NOINLINE void start_game(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds) {
-    uint32_t gid = 0;
-    if (wv::lane() == 0) gid = wv::atomic_add_u32(&P.counters->next_game, 1u);
-    gid = wv::bcast_u32(gid, 0);
+SPRL_DEV void init_game(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds, uint32_t gid) {
     if (gid >= (uint32_t)P.num_games) {
         g.status = ST_IDLE;
         return;
@@ -671,6 +668,63 @@ SPRL_DEV_NOINLINE void start_game(const EngineParams& P, Game& g, int slot, Wave
         gh[0] = s.p0;
         gh[1] = s.p1;
     }
+}
+
+template <class G>
+SPRL_DEV_NOINLINE void start_game(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds) {
+    uint32_t gid = 0;
+    if (wv::lane() == 0) gid = wv::atomic_add_u32(&P.counters->next_game, 1u);
+    gid = wv::bcast_u32(gid, 0);
+    init_game<G>(P, g, slot, lds, gid);
+}
+
+// advanceDecision (UCTTree.hpp:197-210): O(1) — follow the edge, carry its stats as the new root's own N()/W() (Q6),
+// bump the epoch (== clearSubtree), forget the siblings (== pruneChildrenExcept).  Also serves opponentAct
+// (UCTNetworkAgent.hpp:106-108), where the decision node may never have been expanded and the child may not exist.
+template <class G>
+SPRL_DEV void advance_root(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds, int action) {
+    const int l = wv::lane();
+    uint8_t* np = node_at(g.abase, g.root);
+    const NodeHdr h = load_hdr(np);
+    const bool expanded = h.exp_epoch == g.epoch;      // rows of a node that is not active hold no valid statistics
+    uint32_t c;
+    float n_a, w_a;
+    if (G::HAS_PASS && action == PASS_A) {
+        c = h.passChild;
+        n_a = expanded ? h.passN : 0.0f;
+        w_a = expanded ? h.passW : 0.0f;
+    } else {
+        c = wv::bcast_u32((uint32_t)rowC(np)[l], action);
+        n_a = wv::bcast_f32(rowN(np)[l], action);
+        w_a = wv::bcast_f32(rowW(np)[l], action);
+        if (!expanded) { n_a = 0.0f; w_a = 0.0f; }
+    }
+    wv::sync();
+    if (c == SPRL_NONE16) {                   // self-play never gets here (a sampled action has visits > 0)
+        Pos cs;
+        make_child<G>(P, g, lds, pos_of<G>(h), action, g.ply + 1, cs);
+        c = g.n_alloc++;
+        write_new_node<G>(node_at(g.abase, c), cs, action);
+        g.d_created++;
+        w_a = (!P.init_q_zero && (h.flags & F_EVAL)) ? h.value : 0.0f;
+    }
+    g.root = c;
+    g.rootN = n_a;
+    g.rootW = w_a;
+    g.root_player ^= 1u;
+    g.ply += 1;
+    if (G::HIST_CAP > 1) {                     // the new decision node's position joins the real-game history
+        const NodeHdr nh = load_hdr(node_at(g.abase, c));
+        if (l == 0) {
+            lds->hist[g.ply][0] = nh.p0;
+            lds->hist[g.ply][1] = nh.p1;
+        }
+        uint64_t* gh = P.hist_boards + ((size_t)slot * G::HIST_CAP + (size_t)g.ply) * 2;
+        gh[0] = nh.p0;
+        gh[1] = nh.p1;
+    }
+    g.epoch += 1;
+    g.traversals = 0;
 }
 
 // SelfPlay.hpp:110-148: visit pdf, temperature, CDF sample, record, re-root
@@ -725,43 +779,7 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g, int slot, WaveL
     const float x = last * e;
     const uint64_t ge = wv::ballot(l < G::NA && !(cdf < x));
     const int action = ge ? wv::ctz64(ge) : G::A - 1;
-    // advanceDecision (UCTTree.hpp:197-210): O(1) — follow the edge, carry its stats as the new root's own
-    // N()/W() (Q6), bump the epoch (== clearSubtree), forget the siblings (== pruneChildrenExcept).
-    uint32_t c;
-    float n_a, w_a;
-    if (G::HAS_PASS && action == PASS_A) {
-        c = h->passChild;
-        n_a = h->passN;
-        w_a = h->passW;
-    } else {
-        c = wv::bcast_u32((uint32_t)rowC(np)[l], action);
-        n_a = wv::bcast_f32(visits, action);
-        w_a = wv::bcast_f32(rowW(np)[l], action);
-    }
-    if (c == SPRL_NONE16) {                   // cannot happen for a sampled action (visits > 0); kept for safety
-        Pos cs;
-        make_child<G>(P, g, lds, pos_of<G>(*h), action, g.ply + 1, cs);
-        c = g.n_alloc++;
-        write_new_node<G>(node_at(g.abase, c), cs, action);
-        w_a = (h->flags & F_EVAL) ? h->value : 0.0f;
-    }
-    g.root = c;
-    g.rootN = n_a;
-    g.rootW = w_a;
-    g.root_player ^= 1u;
-    g.ply += 1;
-    if (G::HIST_CAP > 1) {                     // the new decision node's position joins the real-game history
-        const NodeHdr nh = load_hdr(node_at(g.abase, c));
-        if (l == 0) {
-            lds->hist[g.ply][0] = nh.p0;
-            lds->hist[g.ply][1] = nh.p1;
-        }
-        uint64_t* gh = P.hist_boards + ((size_t)slot * G::HIST_CAP + (size_t)g.ply) * 2;
-        gh[0] = nh.p0;
-        gh[1] = nh.p1;
-    }
-    g.epoch += 1;
-    g.traversals = 0;
+    advance_root<G>(P, g, slot, lds, action);
     g.d_plies++;
 }
 
@@ -769,11 +787,7 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g, int slot, WaveL
 // one game slot, up to P.rounds rounds
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
-    GameCtl* ctl = P.ctl + slot;
-    Game g;
-    g.status = ctl->status;
-    if (g.status == ST_IDLE || g.status == ST_ERROR) return;
+SPRL_DEV void game_load(const EngineParams& P, int slot, GameCtl* ctl, WaveLds<G>* lds, Game& g) {
     g.rng.state = ctl->rng_state;
     g.rng.inc = ctl->rng_inc;
     g.game_id = ctl->game_id;
@@ -796,7 +810,6 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
     g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * SPRL_NODE_BYTES;
     wv::sync();
 
-    SPRL_TIC(t_all);
     if (G::HIST_CAP > 1 && g.status == ST_ACTIVE) {          // real-game positions 0..ply back into LDS
         const uint64_t* gh = P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
         for (int i = wv::lane(); i <= g.ply; i += 64) {
@@ -805,33 +818,10 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
         }
         wv::sync();
     }
-    if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);
+}
 
-    for (int round = 0; round < P.rounds && g.status == ST_ACTIVE; ++round) {
-        { SPRL_TIC(t_f); if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl); SPRL_TOC(g.cyc_finish, t_f); }
-        // while (traversals < numTraversals) ... ; then the move; then the next ply's search begins
-        bool idle = false;
-        while (g.traversals >= P.num_traversals) {
-            { SPRL_TIC(t_m); play_move<G>(P, g, slot, lds); SPRL_TOC(g.cyc_move, t_m); }
-            if (g.status != ST_ACTIVE) break;
-            const NodeHdr rh = load_hdr(node_at(g.abase, g.root));
-            if (rh.flags & F_TERMINAL) {                          // SelfPlay.hpp:85,151
-                P.rec_nplies[g.game_id] = g.ply;
-                P.rec_winner[g.game_id] = rh.winner;
-                g.d_games++;
-                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
-                start_game<G>(P, g, slot, lds);
-                if (g.status != ST_ACTIVE) { idle = true; break; }
-            }
-        }
-        if (idle || g.status != ST_ACTIVE) break;
-        if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) {
-            if (!compact_arena<G>(P, g)) break;
-            if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
-        }
-        { SPRL_TIC(t_s); select_batch<G>(P, g, slot, ctl, lds); SPRL_TOC(g.cyc_select, t_s); }
-    }
-
+SPRL_DEV void game_store(GameCtl* ctl, Game& g, unsigned long long t_all) {
+    (void)t_all;
     ctl->status = g.status;
     ctl->rng_state = g.rng.state;
     ctl->rng_inc = g.rng.inc;
@@ -870,7 +860,137 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
         t.cyc_lvl_wait += g.cyc_lvl_wait; t.cyc_lvl_pick += g.cyc_lvl_pick; t.cyc_lvl_desc += g.cyc_lvl_desc;
 #endif
     }
+}
+
+template <class G>
+SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
+    GameCtl* ctl = P.ctl + slot;
+    Game g;
+    g.status = ctl->status;
+    if (g.status == ST_IDLE || g.status == ST_ERROR) return;
+    game_load<G>(P, slot, ctl, lds, g);
+#if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
+    const unsigned long long t_all = __builtin_amdgcn_s_memtime();
+#else
+    const unsigned long long t_all = 0;
+#endif
+    if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);
+
+    for (int round = 0; round < P.rounds && g.status == ST_ACTIVE; ++round) {
+        { SPRL_TIC(t_f); if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl); SPRL_TOC(g.cyc_finish, t_f); }
+        // while (traversals < numTraversals) ... ; then the move; then the next ply's search begins
+        bool idle = false;
+        while (g.traversals >= P.num_traversals) {
+            { SPRL_TIC(t_m); play_move<G>(P, g, slot, lds); SPRL_TOC(g.cyc_move, t_m); }
+            if (g.status != ST_ACTIVE) break;
+            const NodeHdr rh = load_hdr(node_at(g.abase, g.root));
+            if (rh.flags & F_TERMINAL) {                          // SelfPlay.hpp:85,151
+                P.rec_nplies[g.game_id] = g.ply;
+                P.rec_winner[g.game_id] = rh.winner;
+                g.d_games++;
+                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
+                start_game<G>(P, g, slot, lds);
+                if (g.status != ST_ACTIVE) { idle = true; break; }
+            }
+        }
+        if (idle || g.status != ST_ACTIVE) break;
+        if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) {
+            if (!compact_arena<G>(P, g)) break;
+            if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
+        }
+        { SPRL_TIC(t_s); select_batch<G>(P, g, slot, ctl, lds); SPRL_TOC(g.cyc_select, t_s); }
+    }
+
+    game_store(ctl, g, t_all);
     P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
+    if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// match play (Evaluate.cpp:104-170, agents/UCTNetworkAgent.hpp, interface/play.hpp:22-60)
+//
+// Game g of a match is played by TWO trees, one per agent, in slots (pair, pair + n): agent k owns colour
+// k ^ (g & 1) (Evaluate.cpp:126-130).  Only the side to move searches; its move is the first maximum of the visit
+// counts (UCTNetworkAgent.hpp:88-89), applied to its own tree (`act`) and posted — together with the game's RNG
+// state, which the reference keeps in one global stream — to the partner's mailbox.  The partner applies it as
+// `opponentAct` in a LATER launch: kernel boundaries are the only cross-wave ordering the hand-over relies on.
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV void step_match(const EngineParams& P0, int slot, WaveLds<G>* lds) {
+    const int n = P0.num_slots >> 1;
+    const int agent = slot >= n ? 1 : 0;
+    const int partner = agent ? slot - n : slot + n;
+    EngineParams P = P0;
+    P.use_sym = P0.m_use_sym[agent];
+    P.eval_kind = P0.m_eval_kind[agent];
+    P.init_q_zero = P0.m_init_q_zero[agent];
+    GameCtl* ctl = P.ctl + slot;
+    Game g;
+    g.status = ctl->status;
+    if (g.status == ST_IDLE || g.status == ST_ERROR) {
+        P.leaf_count[slot] = 0u;
+        return;
+    }
+    game_load<G>(P, slot, ctl, lds, g);
+    if (g.status == ST_FRESH) init_game<G>(P, g, slot, lds, (uint32_t)(slot - agent * n));
+
+    int round = 0;
+    while (round < P.rounds && g.status == ST_ACTIVE) {
+        if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl);
+        const NodeHdr rh = load_hdr(node_at(g.abase, g.root));
+        if (rh.flags & F_TERMINAL) {                               // play.hpp:34
+            if (agent == 0) {
+                P.rec_nplies[g.game_id] = g.ply;
+                P.rec_winner[g.game_id] = rh.winner;
+                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
+            }
+            g.d_games++;
+            init_game<G>(P, g, slot, lds, g.game_id + (uint32_t)n);   // this pair's next game, if any
+            continue;
+        }
+        if ((int)g.root_player != (agent ^ (int)(g.game_id & 1u))) {
+            const Mailbox mb = P.mailbox[slot];
+            wv::sync();
+            const uint32_t m_ply1 = (uint32_t)(mb.ply_launch & 0xffffffffull), m_launch = (uint32_t)(mb.ply_launch >> 32);
+            if (m_launch != P.launch_seq && m_ply1 == (uint32_t)g.ply + 1u && mb.game == g.game_id) {
+                advance_root<G>(P, g, slot, lds, (int)mb.action);          // opponentAct (UCTNetworkAgent.hpp:106-108)
+                g.rng.state = mb.rng_state;
+                continue;
+            }
+            break;                                                  // the partner is still thinking
+        }
+        if (g.traversals >= P.num_traversals) {
+            uint8_t* np = node_at(g.abase, g.root);
+            const int l = wv::lane();
+            const float visits = l < G::NA ? rowN(np)[l] : -1.0f;
+            const float top = wv::fmax_all(visits);
+            int action = __builtin_ctzll(wv::ballot(visits == top));
+            if (G::HAS_PASS && rh.passN > top) action = PASS_A;        // std::max_element: the first maximum
+            wv::sync();
+            if (g.ply < P.max_plies) P.match_actions[(size_t)g.game_id * (size_t)P.max_plies + (size_t)g.ply] = (int16_t)action;
+            const uint32_t ply1 = (uint32_t)g.ply + 1u;
+            advance_root<G>(P, g, slot, lds, action);                  // act (:101)
+            g.d_plies++;
+            if (l == 0) {
+                Mailbox* mb = P.mailbox + partner;
+                mb->game = g.game_id;
+                mb->action = (uint32_t)action;
+                mb->rng_state = g.rng.state;
+                mb->ply_launch = (uint64_t)ply1 | ((uint64_t)P.launch_seq << 32);
+            }
+            continue;
+        }
+        if (g.n_alloc + (uint32_t)P.max_batch + 2u > (uint32_t)P.node_cap) {
+            if (!compact_arena<G>(P, g)) break;
+            if (g.n_alloc + (uint32_t)P.max_batch + 2u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
+        }
+        select_batch<G>(P, g, slot, ctl, lds);
+        ++round;
+    }
+
+    game_store(ctl, g, 0ull);
+    P.leaf_count[slot] = (g.status == ST_ACTIVE && P.eval_kind == EVAL_NETWORK) ? (uint32_t)g.n_leaves : 0u;
     if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
 }
 

@@ -61,6 +61,13 @@ class Stats(C.Structure):
 
 FORWARD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
 
+INITQ_PARENT, INITQ_ZERO = 0, 1
+
+
+class MatchAgent(C.Structure):
+    _fields_ = [("model", C.c_char_p), ("forward", FORWARD_FN), ("forward_user", C.c_void_p),
+                ("use_symmetry", C.c_int32), ("init_q", C.c_int32)]
+
 _libs = {}
 _hip_runtime = None
 
@@ -111,6 +118,8 @@ def load_library(path=None):
     L.sprl_records_expand.argtypes = [C.POINTER(Records), C.c_void_p, C.c_void_p, C.c_void_p]
     L.sprl_records_expand_boards.argtypes = [C.POINTER(Records), C.c_void_p, C.c_void_p]
     L.sprl_write_npy.argtypes = [C.c_char_p, C.POINTER(Records)]
+    L.sprl_match_play.argtypes = [C.POINTER(Config), C.POINTER(MatchAgent), C.POINTER(MatchAgent), C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     _libs[path] = L
     return L
 
@@ -255,3 +264,50 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+def _match_agent(spec, keep):
+    """spec: dict(model="random"|"heuristic"|path | forward=callable, use_symmetry=bool, parent_q=bool)."""
+    a = MatchAgent()
+    fwd = spec.get("forward")
+    if fwd is not None:
+        def _cb(user, planes, batch, logits, value, fn=fwd):
+            try:
+                return int(fn(planes, batch, logits, value) or 0)
+            except Exception as exc:  # never let an exception cross the C boundary
+                print("forward callback failed:", exc)
+                return -1
+        a.forward = FORWARD_FN(_cb)
+        keep.append(a.forward)
+    else:
+        a.model = os.fsencode(spec["model"])
+    a.use_symmetry = 1 if spec.get("use_symmetry", True) else 0
+    a.init_q = INITQ_PARENT if spec.get("parent_q", True) else INITQ_ZERO
+    return a
+
+
+def play_match(cfg, agent0, agent1, num_games, max_plies=256, lib=None):
+    """Agent-vs-agent games on the device (the reference's Evaluate.exe, cpp/src/Evaluate.cpp).  `cfg` carries the tree
+    options shared by both agents (Evaluate.cpp:94-112: dir_eps 0.25, dir_alpha 0.1, noise on).  Returns
+    (winners int8[num_games] by colour, actions int16[num_games, max_plies] (-1 padded), nplies int32[num_games]);
+    agent k plays colour k ^ (game & 1)."""
+    L = lib or load_library()
+    keep = []
+    a0, a1 = _match_agent(agent0, keep), _match_agent(agent1, keep)
+    winners = np.zeros(num_games, np.int8)
+    nplies = np.zeros(num_games, np.int32)
+    actions = np.full((num_games, max_plies), -1, np.int16)
+    rc = L.sprl_match_play(C.byref(cfg), C.byref(a0), C.byref(a1), num_games, winners.ctypes.data, nplies.ctypes.data,
+                           actions.ctypes.data, max_plies)
+    if rc:
+        raise SprlError(rc, L.sprl_last_error().decode())
+    return winners, actions, nplies
+
+
+def match_score(winners):
+    """Per-agent tallies from colour winners: (agent0 wins, agent1 wins, draws) — Evaluate.cpp:141-160."""
+    w = np.asarray(winners)
+    g = np.arange(w.size)
+    a0 = int(np.sum((w >= 0) & ((w ^ (g & 1)) == 0)))
+    a1 = int(np.sum((w >= 0) & ((w ^ (g & 1)) == 1)))
+    return a0, a1, int(np.sum(w < 0))

@@ -27,6 +27,11 @@ void block_entry(void* arg, int block) {
     sprl::step_game<G>(*P, block, reinterpret_cast<sprl::WaveLds<G>*>(tl_lds));
 }
 template <class G>
+void block_entry_match(void* arg, int block) {
+    const EngineParams* P = (const EngineParams*)arg;
+    sprl::step_match<G>(*P, block, reinterpret_cast<sprl::WaveLds<G>*>(tl_lds));
+}
+template <class G>
 void block_entry_wide(void* arg, int block) {
     const EngineParams* P = (const EngineParams*)arg;
     static_assert(sizeof(sprlw::WaveLdsW<G>) <= sizeof(tl_lds), "emulated LDS too small");
@@ -53,6 +58,14 @@ int launch_step(int game, const EngineParams& P) {
     else if (game == SPRL_GAME_GO19) emu::launch(block_entry_wide<GoN<19>>, &copy, P.num_slots);
     else if (game == SPRL_GAME_GO7W) emu::launch(block_entry_wide<GoN<7>>, &copy, P.num_slots);
     else emu::launch(block_entry<ConnectFour>, &copy, P.num_slots);
+    return 0;
+}
+int launch_match(int game, const EngineParams& P) {
+    EngineParams copy = P;
+    if (game == SPRL_GAME_OTHELLO) emu::launch(block_entry_match<Othello>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO7) emu::launch(block_entry_match<Go7>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_CONNECT_FOUR) emu::launch(block_entry_match<ConnectFour>, &copy, P.num_slots);
+    else return -1;
     return 0;
 }
 int launch_compact(const EngineParams& P, int floats_per_leaf) {

@@ -184,6 +184,25 @@ def g7_g9_network():
     save("g7_decode.npz", boards=boards, players=players, masks=masks, policy=pol, value=val)
 
 
+MATCH_CASES = [  # game, kind0, kind1, games, traversals, batch, queue, sym0, parentQ0, sym1, parentQ1, seed
+    ("othello", 0, 1, 6, 64, 8, 4, 1, 1, 1, 1, 777),
+    ("othello", 0, 1, 4, 100, 8, 4, 0, 0, 1, 1, 778),
+    ("othello", 1, 0, 4, 48, 1, 1, 1, 0, 0, 1, 779),
+    ("c4", 0, 0, 8, 100, 8, 4, 1, 1, 0, 0, 780),
+    ("c4", 0, 0, 6, 40, 4, 2, 0, 1, 1, 0, 781),
+]
+
+
+def g10_matches():
+    """Evaluate.cpp-style agent-vs-agent games through the reference's UCTNetworkAgent + playGame."""
+    out = {"cases": np.array([[c[1:][i] for i in range(11)] for c in MATCH_CASES], np.int64),
+           "games": np.array([c[0] for c in MATCH_CASES])}
+    for i, (game, k0, k1, n, trav, mb, mq, s0, p0, s1, p1, seed) in enumerate(MATCH_CASES):
+        w, a, npl = pyref.match(game, k0, k1, n, trav, mb, mq, s0, p0, s1, p1, seed, 1, 160)
+        out[f"winners{i}"], out[f"actions{i}"], out[f"nplies{i}"] = w, a, npl
+    save("g10_matches.npz", **out)
+
+
 if __name__ == "__main__":
     assert pyref.available() and pyref.available(True), "run `make -C oracle ref ref_torch` first"
     g6_rng()
@@ -192,3 +211,4 @@ if __name__ == "__main__":
     g4_search()
     g5_games()
     g7_g9_network()
+    g10_matches()

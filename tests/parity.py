@@ -67,3 +67,39 @@ def toy_forward_numpy(planes, A):
     logits = np.stack([x[i] @ w for i in range(n)]).astype(np.float32)
     value = np.tanh(np.array([x[i] @ v for i in range(n)])).astype(np.float32)
     return logits, value
+
+
+MATCH_EVAL = {"random": po.EVAL_RANDOM, "heuristic": po.EVAL_HEURISTIC}
+
+
+def match_config(lib, game, **kw):
+    """Tree options of the reference's Evaluate.cpp:94-112 (eps 0.25, alpha 0.1, noise on; u-weight 1.0 is the
+    UCTTree default there)."""
+    base = dict(dir_eps=0.25, dir_alpha=0.1, u_weight=1.0, add_noise=1)
+    base.update(kw)
+    return E.default_config(game, lib, **base)
+
+
+def check_match(lib, game, agents, num_games, seed=11, forwards=(None, None), oracle_forwards=(None, None), **cfg_kw):
+    """agents: two dicts(model=..., use_symmetry=..., parent_q=...).  Device match == oracle match, move for move."""
+    cfg = match_config(lib, game, seed=seed, **cfg_kw)
+    specs = []
+    for a, f in zip(agents, forwards):
+        s = dict(a)
+        if f is not None:
+            s["forward"] = f
+        specs.append(s)
+    winners, actions, nplies = E.play_match(cfg, specs[0], specs[1], num_games, max_plies=160, lib=lib)
+    ocfg = []
+    for a, of in zip(agents, oracle_forwards):
+        kind = po.EVAL_CALLBACK if of is not None else MATCH_EVAL[a["model"]]
+        ocfg.append(po.make_config(OGAME[game], cfg.num_traversals, max_batch=cfg.max_batch, max_queue=cfg.max_queue,
+                                   dir_eps=cfg.dir_eps, dir_alpha=cfg.dir_alpha, u_weight=cfg.u_weight,
+                                   use_sym=1 if a.get("use_symmetry", True) else 0, add_noise=cfg.add_noise,
+                                   eval_kind=kind, math_mode=po.MATH_PORTABLE, mask_frame=cfg.mask_frame, forward=of,
+                                   init_q=0 if a.get("parent_q", True) else 1))
+    ow, oa, on = po.match(ocfg[0], ocfg[1], num_games, seed, cfg.stream_base, max_plies=160)
+    assert (nplies == on).all(), (nplies, on)
+    assert (actions == oa).all()
+    assert (winners == ow).all()
+    return winners, actions, nplies

@@ -176,3 +176,62 @@ def test_error_codes(emu):
         eng.step(1)                     # begin() not called
     assert ei.value.code == -5
     eng.close()
+
+
+# ---- match play (Evaluate.cpp): two trees per game, move + RNG hand-over between launches ----
+
+def test_match_c4_random_vs_random(emu):
+    agents = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="random", use_symmetry=False, parent_q=False)]
+    w, _, n = parity.check_match(emu, "c4", agents, 5, concurrent_games=2, num_traversals=40)
+    assert (n > 6).all()
+
+
+def test_match_othello_random_vs_heuristic(emu):
+    agents = [dict(model="random", use_symmetry=True, parent_q=False), dict(model="heuristic", use_symmetry=True, parent_q=True)]
+    w, _, n = parity.check_match(emu, "othello", agents, 4, concurrent_games=4, num_traversals=32, seed=777)
+    assert sum(E.match_score(w)) == 4 and (n >= 9).all()
+
+
+def test_match_go7_and_compaction(emu):
+    agents = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="random", use_symmetry=True, parent_q=True)]
+    parity.check_match(emu, "go", agents, 2, concurrent_games=2, num_traversals=24, max_batch=4, max_queue=2, node_cap=200)
+
+
+def test_match_network_agents_toy_forward(emu):
+    """Two network agents with DIFFERENT forwards: rows of the dense batch are split per agent."""
+    A = 65
+
+    def make(scale):
+        def engine_forward(planes_ptr, batch, logits_ptr, value_ptr):
+            planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_float)), shape=(batch, 3, 8, 8))
+            lo, va = parity.toy_forward_numpy(planes, A)
+            np.ctypeslib.as_array(C.cast(logits_ptr, C.POINTER(C.c_float)), shape=(batch, A))[:] = lo * np.float32(scale)
+            np.ctypeslib.as_array(C.cast(value_ptr, C.POINTER(C.c_float)), shape=(batch,))[:] = va
+            return 0
+
+        def oracle_forward(x):
+            lo, va = parity.toy_forward_numpy(x, A)
+            return lo * np.float32(scale), va
+        return engine_forward, po.make_forward(oracle_forward, po.GAME_OTHELLO)
+
+    e0, o0 = make(1.0)
+    e1, o1 = make(0.25)
+    agents = [dict(model="net", use_symmetry=True, parent_q=True), dict(model="net", use_symmetry=False, parent_q=True)]
+    parity.check_match(emu, "othello", agents, 3, concurrent_games=2, num_traversals=20, forwards=(e0, e1),
+                       oracle_forwards=(o0, o1))
+
+
+def test_match_mixed_network_and_random(emu):
+    A = 43
+
+    def engine_forward(planes_ptr, batch, logits_ptr, value_ptr):
+        planes = np.ctypeslib.as_array(C.cast(planes_ptr, C.POINTER(C.c_float)), shape=(batch, 3, 6, 7))
+        lo, va = parity.toy_forward_numpy(planes, A)
+        np.ctypeslib.as_array(C.cast(logits_ptr, C.POINTER(C.c_float)), shape=(batch, A))[:] = lo
+        np.ctypeslib.as_array(C.cast(value_ptr, C.POINTER(C.c_float)), shape=(batch,))[:] = va
+        return 0
+    A = 7
+    cb = po.make_forward(lambda x: parity.toy_forward_numpy(x, A), po.GAME_C4)
+    agents = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="net", use_symmetry=True, parent_q=False)]
+    parity.check_match(emu, "c4", agents, 4, concurrent_games=3, num_traversals=30, forwards=(None, engine_forward),
+                       oracle_forwards=(None, cb))

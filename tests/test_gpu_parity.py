@@ -214,3 +214,58 @@ def test_in_process_selfplay_training_loop(lib, tmp_path):
     assert str(loop.window.training_tensors(2)[0].device).startswith("cuda")
     assert hist[2]["best_val"] < hist[0]["best_val"] + 1.0          # training ran and produced finite losses
     assert all(np.isfinite(h["best_val"]) for h in hist)
+
+
+# ---- match play (Evaluate.cpp) on the device ----
+
+def test_match_othello_random_vs_heuristic(lib):
+    agents = [dict(model="random", use_symmetry=True, parent_q=False), dict(model="heuristic", use_symmetry=True, parent_q=True)]
+    parity.check_match(lib, "othello", agents, 12, concurrent_games=8, num_traversals=100, seed=777)
+
+
+def test_match_c4_and_go7(lib):
+    a = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="random", use_symmetry=False, parent_q=False)]
+    parity.check_match(lib, "c4", a, 16, concurrent_games=16, num_traversals=100)
+    parity.check_match(lib, "go", a, 4, concurrent_games=4, num_traversals=64, node_cap=300, spare_arenas=4)
+
+
+def test_match_two_network_agents_toy_forward(lib):
+    """Both agents evaluate through forward hooks on DEVICE buffers; the dense batch is split per agent."""
+    import torch
+    A = 65
+
+    class _Arr:
+        def __init__(self, ptr, shape):
+            self.__cuda_array_interface__ = dict(shape=shape, typestr="<f4", data=(ptr, False), version=2)
+
+    def make(scale):
+        def fwd(planes_ptr, batch, logits_ptr, value_ptr):
+            x = torch.as_tensor(_Arr(planes_ptr, (batch, 3, 8, 8)), device="cuda").cpu().numpy()
+            lo, va = parity.toy_forward_numpy(x, A)
+            torch.as_tensor(_Arr(logits_ptr, (batch, A)), device="cuda").copy_(torch.from_numpy(lo * np.float32(scale)))
+            torch.as_tensor(_Arr(value_ptr, (batch,)), device="cuda").copy_(torch.from_numpy(va))
+            torch.cuda.synchronize()
+            return 0
+
+        def ofwd(x):
+            lo, va = parity.toy_forward_numpy(x, A)
+            return lo * np.float32(scale), va
+        return fwd, po.make_forward(ofwd, po.GAME_OTHELLO)
+
+    e0, o0 = make(1.0)
+    e1, o1 = make(0.25)
+    agents = [dict(model="net", use_symmetry=True, parent_q=True), dict(model="net", use_symmetry=False, parent_q=True)]
+    parity.check_match(lib, "othello", agents, 3, concurrent_games=3, num_traversals=24, forwards=(e0, e1),
+                       oracle_forwards=(o0, o1))
+
+
+def test_match_traced_models(lib, traced_model, tmp_path):
+    """Two traced CNNs through the LibTorch-ROCm plugin: games are legal and complete, colours alternate."""
+    from sprl_amd.network import make_network, trace_to_file
+    other = trace_to_file(make_network("othello", 1, 32, seed=5), str(tmp_path / "traced_b.pt"), "othello")
+    cfg = parity.match_config(lib, "othello", concurrent_games=32, num_traversals=48, seed=3)
+    w, actions, n = E.play_match(cfg, dict(model=traced_model), dict(model=other, parent_q=False), 48, lib=lib)
+    assert (n >= 9).all() and (n <= 128).all()
+    assert sum(E.match_score(w)) == 48
+    for g in range(48):                      # replay every game with the oracle's rules: every move legal, same end
+        assert po.replay_winner(po.GAME_OTHELLO, actions[g, :n[g]]) == w[g]

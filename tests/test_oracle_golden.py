@@ -216,3 +216,32 @@ def test_live_reference_whole_games(game, kind, trav, mb, mq, alpha, ngames):
     for k in ("boards", "players", "sizes", "outcomes"):
         assert (o[k] == r[k]).all()
     assert (bits(o["dists"]) == bits(r["dists"])).all()
+
+
+def _match_cfg(game, kind, trav, mb, mq, sym, parent_q):
+    # tree options of Evaluate.cpp:94-112 (eps 0.25, alpha 0.1, noise on, default u-weight 1.0)
+    return po.make_config(GAMES[game], trav, max_batch=mb, max_queue=mq, dir_eps=0.25, dir_alpha=0.1, u_weight=1.0,
+                          use_sym=sym, add_noise=1, eval_kind=kind, init_q=0 if parent_q else 1)
+
+
+def test_g10_matches(golden):
+    """Agent-vs-agent games (Evaluate.cpp through UCTNetworkAgent + playGame): move lists, lengths and winners."""
+    g = golden("g10_matches.npz")
+    for i, game in enumerate(g["games"]):
+        k0, k1, n, trav, mb, mq, s0, p0, s1, p1, seed = (int(v) for v in g["cases"][i])
+        w, a, npl = po.match(_match_cfg(str(game), k0, trav, mb, mq, s0, p0), _match_cfg(str(game), k1, trav, mb, mq, s1, p1),
+                             n, seed, 1, 160)
+        assert (npl == g[f"nplies{i}"]).all()
+        assert (a == g[f"actions{i}"]).all()
+        assert (w == g[f"winners{i}"]).all()
+        for k in range(n):
+            assert po.replay_winner(GAMES[str(game)], a[k, :npl[k]]) == w[k]
+
+
+@pytest.mark.skipif(not pyref.available(), reason="prebuilt reference library not present")
+def test_live_reference_matches():
+    for game, k0, k1 in (("othello", 1, 0), ("c4", 0, 0)):
+        r = pyref.match(game, k0, k1, 3, 72, 8, 4, 1, 0, 1, 1, 31337, 5, 160)
+        o = po.match(_match_cfg(game, k0, 72, 8, 4, 1, 0), _match_cfg(game, k1, 72, 8, 4, 1, 1), 3, 31337, 5, 160)
+        for x, y in zip(r, o):
+            assert (x == y).all()
