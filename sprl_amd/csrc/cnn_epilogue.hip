@@ -40,19 +40,22 @@ __global__ void __launch_bounds__(256) bn_relu_kernel(float4* __restrict__ x, co
 template <int OC>
 __global__ void __launch_bounds__(256) heads_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ out_p,
-                                                    float* __restrict__ out_v, int64_t n_pos, int C, int HW, int PC) {
+                                                    float* __restrict__ out_v, int64_t n_pos, int C, int HW, int PC, int Wd) {
+    // Wd > 0: x is in layout W of cnn_wino.hip (board width Wd), else NCHW
     extern __shared__ float wsh[];                       // [OC][C] then [OC] biases
     for (int i = threadIdx.x; i < OC * C + OC; i += blockDim.x) wsh[i] = i < OC * C ? w[i] : bias[i - OC * C];
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW;
         const int pos = (int)(i - b * HW);
-        const float* xp = x + b * (int64_t)C * HW + pos;
+        const int row = Wd > 0 ? pos / Wd : 0, col = Wd > 0 ? pos % Wd : 0;
+        const float* xp = Wd > 0 ? x + b * 4096 + (row & 3) * 64 + ((row >> 2) * 2 + (col >> 2)) * 4 + (col & 3)
+                                 : x + b * (int64_t)C * HW + pos;
         float acc[OC];
 #pragma unroll
         for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
         for (int c = 0; c < C; ++c) {
-            const float v = xp[(int64_t)c * HW];
+            const float v = Wd > 0 ? xp[(4 * (c >> 4) + (c & 3)) * 256 + ((c >> 2) & 3) * 16] : xp[(int64_t)c * HW];
 #pragma unroll
             for (int o = 0; o < OC; ++o) acc[o] += wsh[o * C + c] * v;
         }
@@ -65,16 +68,76 @@ __global__ void __launch_bounds__(256) heads_kernel(const float* __restrict__ x,
         }
     }
 }
+// Stem convolution (P input planes -> 64 channels, 3x3, padding 1) + folded BatchNorm/bias + ReLU, written in layout W
+// (cnn_wino.hip) for the trunk kernels.  K = 9 P is tiny (27 for Othello / Connect Four), so this is plain VALU work:
+// thread = one board cell, the 3x3xP patch in registers, the weights wave-uniform (scalar loads), 64 channels per thread.
+// Cells of the 8x8 frame that are off an H x W board are written as zeros (the trunk relies on it).
+template <int P>
+__global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ planes, const float* __restrict__ w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   float* __restrict__ y, int batch, int H, int W) {
+    __shared__ float img[4][P][100];                   // zero-bordered 10x10 images
+    const int tid = (int)threadIdx.x;
+    const int n0 = (int)blockIdx.x * 4;
+    for (int i = tid; i < 4 * P * 100; i += 256) (&img[0][0][0])[i] = 0.0f;
+    __syncthreads();
+    const int HW = H * W;
+    for (int e = tid; e < 4 * P * HW; e += 256) {
+        const int b = e / (P * HW), r = e % (P * HW), p = r / HW, cell = r % HW;
+        if (n0 + b < batch) img[b][p][(cell / W + 1) * 10 + cell % W + 1] = planes[(size_t)(n0 + b) * P * HW + r];
+    }
+    __syncthreads();
+    const int b = tid >> 6, cell = tid & 63;
+    const int i = cell >> 4, tile = (cell >> 2) & 3, j = cell & 3;
+    const int row = 4 * (tile >> 1) + i, col = 4 * (tile & 1) + j;
+    const int n = n0 + b;
+    float d[P][9];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) d[p][t] = img[b][p][(row + t / 3) * 10 + col + t % 3];
+    const bool on_board = row < H && col < W;
+    if (n >= batch) return;
+    float* yo = y + (size_t)n * 4096 + i * 64 + tile * 4 + j;
+    for (int g = 0; g < 16; ++g) {
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs) {
+            const int k = 16 * (g >> 2) + 4 * cs + (g & 3);
+            const float* wk = w + (size_t)k * P * 9;
+            float acc = 0.0f;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc += wk[p * 9 + t] * d[p][t];
+            acc = acc * scale[k] + shift[k];
+            yo[g * 256 + cs * 16] = on_board ? (acc > 0.0f ? acc : 0.0f) : 0.0f;
+        }
+    }
+}
 }  // namespace
 
+// planes: [batch][P][H][W] (the engine's dense network batch), w: [64][P][3][3], y: layout W.  -1: no kernel for this P.
+extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                   int batch, int P, int H, int W, void* stream) {
+    if (batch <= 0) return 0;
+    if (H > 8 || W > 8) return -1;
+    const dim3 grid((unsigned)((batch + 3) / 4)), block(256);
+    if (P == 3) hipLaunchKernelGGL(stem_kernel<3>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W);
+    else if (P == 17) hipLaunchKernelGGL(stem_kernel<17>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W);
+    else return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// board_w > 0: x is in layout W (cnn_wino.hip; needs C == 64), board_w == 0: NCHW
 extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const float* bias, float* out_p, float* out_v,
-                                       int64_t batch, int C, int HW, int PC, int VC, void* stream) {
+                                       int64_t batch, int C, int HW, int PC, int VC, int board_w, void* stream) {
+    if (board_w > 0 && C != 64) return -1;
     const int OC = PC + VC;
     const int64_t n_pos = batch * HW;
     int64_t blocks = (n_pos + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     const size_t lds = (size_t)(OC * C + OC) * sizeof(float);
-#define LAUNCH(N) hipLaunchKernelGGL(heads_kernel<N>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, w, bias, out_p, out_v, n_pos, C, HW, PC)
+#define LAUNCH(N) hipLaunchKernelGGL(heads_kernel<N>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, w, bias, out_p, out_v, n_pos, C, HW, PC, board_w)
     switch (OC) {
     case 2: LAUNCH(2); break;
     case 3: LAUNCH(3); break;

@@ -1,0 +1,317 @@
+// cnn_wino.hip — the trunk convolution of the policy/value CNN as a hand-written gfx950 kernel.
+//
+// conv3x3 (64 -> 64 channels, padding 1, boards up to 8x8: grid_networks.py:8-27) + BatchNorm/bias (folded scale and
+// shift) + optional residual + ReLU in ONE launch, fp32 end to end:
+//   Winograd F(4x4, 3x3): a board is 2x2 output tiles of 4x4; per tile and channel the 6x6 input patch d is
+//   transformed (V = B^T d B), the 36 transform positions are 36 independent [64 x 64] x [64 x tiles] products on the
+//   fp32 matrix cores (v_mfma_f32_16x16x4_f32), and Y = A^T M A is transformed back.  4x fewer multiplies than the
+//   direct convolution (2.25x fewer than the F(2x2,3x3) library kernel it replaces).
+//
+// Activation layout "W", chosen so that both ends of this kernel move whole 256-byte rows:
+//   x[n][g][i][cs][tile][j],  channel k = 16 (g >> 2) + 4 cs + (g & 3),  cell (row, col) = (4 ty + i, 4 tx + j),
+//   tile = 2 ty + tx; 4096 floats per board, cells outside an H x W board hold zeros.
+// A channel quad of the K loop (one MFMA K step) is one group g: 1 KB contiguous per board.
+//
+// Workgroup = 8 waves (2 per SIMD) = 8 boards = 32 tiles, K loop over the 16 groups:
+//   * activations: two groups x 8 boards per chunk, zero-bordered 10x10 images in LDS (double buffered; strides chosen
+//     so that the 32 lanes of a bank group read 32 different banks);
+//   * B operand: for every chunk the 512 threads build V[2 groups][36][4 ch][32 tiles] ONCE into LDS (thread = one
+//     channel, one tile, three of the six transform rows: two 1-D transforms of its 6x6 patch, ~80 VALU operations),
+//     double buffered, in the lane order the MFMA wants, so a B fetch is one conflict-free ds_read;
+//   * A operand: weights pre-transformed on the host (U = G g G^T) and stored in lane order, so every A fetch is one
+//     coalesced 256-byte load from L2 (590 KB per layer, shared by every workgroup), used for both tile blocks;
+//   * wave (kb, half) accumulates output channels 16kb..16kb+15 for transform positions 18half..18half+17 and all
+//     32 tiles: 36 accumulator tiles of 16x16 (144 registers).  Producing V(s+1) (VALU + LDS) overlaps the MFMAs
+//     of V(s) inside a wave and across the two waves of a SIMD.
+// Output: the two waves of a kb swap halves through LDS (16-byte accesses), so that each lane then holds all 36
+// positions of its four (channel, tile) pairs: inverse transform in registers, scale/shift, residual, ReLU, and
+// 16-byte stores that are contiguous over 16 lanes (256-byte rows of layout W).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int NIMG = 8;                  // boards per workgroup
+constexpr int NTHR = 512;
+constexpr int RS = 10;                   // row stride of a zero-bordered board image
+constexpr int IA = 112, IB = 226;        // board b sits at (b & 1) * IA + (b >> 1) * IB   (== 16 and 2 mod 32)
+constexpr int CS = 929;                  // channel-slot stride (== 1 mod 32)
+constexpr int IN_BUF = 8 * CS;           // 8 channel slots = 2 groups
+constexpr int V_BUF = 36 * 128;          // V[p][tb][c_sub][16 tiles]
+constexpr int LDS_FLOATS = 2 * IN_BUF + 4 * V_BUF;       // 133 KB; the output exchange (72 KB) reuses it
+
+__device__ __forceinline__ int board_off(int b) { return (b & 1) * IA + (b >> 1) * IB; }
+
+// Y = A^T m A for one (channel, tile): rows of the 4x4 output
+__device__ __forceinline__ void inverse_transform(const float (&m)[6][6], float (&o)[4][4]) {
+    float tm[4][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const float s12 = m[1][b] + m[2][b], d12 = m[1][b] - m[2][b], s34 = m[3][b] + m[4][b], d34 = m[3][b] - m[4][b];
+        tm[0][b] = m[0][b] + s12 + s34;
+        tm[1][b] = d12 + 2.0f * d34;
+        tm[2][b] = s12 + 4.0f * s34;
+        tm[3][b] = d12 + 8.0f * d34 + m[5][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s12 = tm[i][1] + tm[i][2], d12 = tm[i][1] - tm[i][2], s34 = tm[i][3] + tm[i][4], d34 = tm[i][3] - tm[i][4];
+        o[i][0] = tm[i][0] + s12 + s34;
+        o[i][1] = d12 + 2.0f * d34;
+        o[i][2] = s12 + 4.0f * s34;
+        o[i][3] = d12 + 8.0f * d34 + tm[i][5];
+    }
+}
+
+// ABL: ablation switches for tools/wino_ablate.hip only (0 in the product): 1 no output stage, 2 no V production,
+// 4 no weight loads, 8 no MFMAs, 16 no activation loads
+template <int H, int W, int ABL = 0>
+__global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ res, float* __restrict__ y, int batch,
+                                                           int relu) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float* const in_buf = lds;                        // [2][IN_BUF]
+    float* const v_buf = lds + 2 * IN_BUF;            // [2 phases][2 groups][V_BUF]
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c_sub = lane >> 4, tl = lane & 15;
+    const int n0 = (int)blockIdx.x * NIMG;
+    // producer role: group gl of the chunk, tile block tbp, transform rows xi in 3wa..3wa+2 (all six nu)
+    const int gl = wave & 1, tbp = (wave >> 1) & 1, wa = wave >> 2;
+    // consumer role: output channels 16kb.., positions 18half..
+    const int kb = wave & 3, half = wave >> 2;
+
+    for (int i = tid; i < 2 * IN_BUF; i += NTHR) lds[i] = 0.0f;   // borders stay zero for the whole kernel
+
+    f4 acc[18][2];
+#pragma unroll
+    for (int q = 0; q < 18; ++q)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[q][tb] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    // chunk = groups 2c, 2c+1 of 8 boards: 1024 float4, two per thread.  float4 f of a board's chunk:
+    // f = ((gl * 4 + i) * 4 + cs) * 4 + tile  ->  channel slot gl * 4 + cs, row 4 ty + i, columns 4 tx .. 4 tx + 3
+    f4 pre[2][2];                                     // two register sets: a chunk's loads get 1.5 phases to land
+    int ldst[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int f = tid + NTHR * it;
+        const int b = f >> 7, rem = f & 127;
+        const int gl = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
+        ldst[it] = (gl * 4 + cs) * CS + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
+    }
+    auto gload = [&](int chunk, f4 (&pre)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int f = tid + NTHR * it;
+            const int n = n0 + (f >> 7);
+            pre[it] = (ABL & 16) ? (f4){ 1.0f, 1.0f, 1.0f, 1.0f }
+                      : n < batch ? __builtin_nontemporal_load((const f4*)(x + (size_t)n * 4096 + (size_t)chunk * 512 + (size_t)(f & 127) * 4))
+                                  : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+        }
+    };
+    auto lstore = [&](float* buf, const f4 (&pre)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = pre[it][j];
+    };
+    // V of chunk c (groups 2c, 2c+1): this thread's channel slot gl * 4 + c_sub, tile 16 tbp + tl, rows 3wa..3wa+2 of
+    // V = B^T d B.  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]: rows 0-2
+    // need patch rows 0-4, rows 3-5 need patch rows 1-5, and rows 5 and 0 are the same stencil one step apart.
+    const int patch0 = (gl * 4 + c_sub) * CS + board_off(tbp * 4 + (tl >> 2)) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
+    const int vdst0 = gl * V_BUF + (3 * wa) * 6 * 128 + tbp * 64 + lane;
+    auto produce = [&](int c) {
+        const float* pp = in_buf + (c & 1) * IN_BUF + patch0;
+        float* vd = v_buf + (c & 1) * 2 * V_BUF + vdst0;
+        float wr[3][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
+            const float st = 4.0f * e0 - 5.0f * e2 + e4;
+            if (wa == 0) {
+                const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                wr[0][j] = st;
+                wr[1][j] = p + q;
+                wr[2][j] = p - q;
+            } else {
+                const float p = e3 - e1, q = 2.0f * (e2 - e0);
+                wr[0][j] = p + q;
+                wr[1][j] = p - q;
+                wr[2][j] = st;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+            const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
+            vd[(r * 6 + 0) * 128] = 4.0f * w0 - 5.0f * w2 + w4;
+            vd[(r * 6 + 1) * 128] = p + q;
+            vd[(r * 6 + 2) * 128] = p - q;
+            vd[(r * 6 + 3) * 128] = p2 + q2;
+            vd[(r * 6 + 4) * 128] = p2 - q2;
+            vd[(r * 6 + 5) * 128] = 4.0f * w1 - 5.0f * w3 + w5;
+        }
+    };
+    // A operand: U2[p][s][kb][lane], p = xi * 6 + nu, lane -> (k = 16kb + lane%16, input channel = slot lane/16 of group s)
+    const float* ua = u + (size_t)(18 * half) * (16 * 4 * 64) + kb * 64 + lane;
+    const float* vsrc = v_buf + (18 * half) * 128 + lane;
+
+    // weights and MFMAs of one chunk (two groups) for this wave, in six slices of six transform positions; the weight
+    // loads run three slices (18 registers) ahead of the MFMAs that use them
+    auto aload = [&](int c, int k, float (&a)[6]) {
+        const int s = 2 * c + k / 3, q0 = (k % 3) * 6;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a[q] = (ABL & 4) ? (float)(q + s) : ua[(size_t)(q0 + q) * (16 * 4 * 64) + s * 256];
+    };
+    auto mma = [&](const float* vs, int k, const float (&a)[6]) {
+        const float* vk = vs + (k / 3) * V_BUF + (k % 3) * 6 * 128;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float b0 = vk[q * 128], b1 = vk[q * 128 + 64];
+            const int qq = (k % 3) * 6 + q;
+            if (ABL & 8) {
+                acc[qq][0][0] += a[q] * b0;
+                acc[qq][1][0] += a[q] * b1;
+            } else {
+                acc[qq][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b0, acc[qq][0], 0, 0, 0);
+                acc[qq][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b1, acc[qq][1], 0, 0, 0);
+            }
+        }
+    };
+    // phase c: MFMAs on V(c) while V(c+1) is built; chunk c+2 goes to LDS, chunk c+4 is requested from HBM.
+    // Memory-counter order matters (vmcnt retires in order): the HBM request is issued AFTER the weight loads, so waiting
+    // for the weights never waits for HBM.  The two waves of a SIMD (half 0 / half 1) run produce and MFMA in opposite
+    // order, so one does VALU/LDS work while the other feeds the matrix core.
+    auto phase = [&](int c, f4 (&pset)[2]) {
+        if (c + 2 < 8) lstore(in_buf + (c & 1) * IN_BUF, pset);          // in_buf[c & 1]: V(c) was built in phase c - 1
+        const float* vs = vsrc + (c & 1) * 2 * V_BUF;
+        if (half == 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float a[3][6];
+        aload(c, 0, a[0]);
+        aload(c, 1, a[1]);
+        aload(c, 2, a[2]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            mma(vs, k, a[k % 3]);
+            if (k + 3 < 6) aload(c, k + 3, a[k % 3]);
+            if (k == 2 && c + 4 < 8) gload(c + 4, pset);     // after the chunk's last weight request (vmcnt order)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (half != 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
+        __syncthreads();
+    };
+
+    gload(0, pre[0]);
+    gload(1, pre[1]);
+    __syncthreads();                                   // zero fill done
+    lstore(in_buf, pre[0]);
+    lstore(in_buf + IN_BUF, pre[1]);
+    gload(2, pre[0]);
+    gload(3, pre[1]);
+    __syncthreads();
+    produce(0);
+    __syncthreads();
+    for (int c = 0; c < 8; c += 2) {
+        phase(c, pre[0]);
+        phase(c + 1, pre[1]);
+    }
+
+    if (ABL & 1) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 18; ++q) sum += acc[q][0][0] + acc[q][1][1] + acc[q][0][2] + acc[q][1][3];
+        if (sum == 123.456f) y[tid] = sum;
+        return;
+    }
+
+    // ---- the two waves of a kb swap halves: wave (kb, half) ends up with all 36 positions of tile block `half` ----
+    // (written twice, once per value of the wave-uniform `half`, so that every register index is static).  Two rounds of
+    // two accumulator components each keep the live registers under the 256 budget with the residual rows in flight.
+    f2* const xch = (f2*)lds;                          // [8 waves][18][64 lanes] float2 = 72 KB
+    const int partner = wave ^ 4;
+    auto finish = [&](auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
+        const int t = 16 * HALF + tl;                  // tile of this lane
+        const int n = n0 + (t >> 2), tile = t & 3, ty = tile >> 1, tx = tile & 1;
+        const size_t plane0 = (size_t)n * 4096 + (size_t)(4 * kb) * 256 + (size_t)(c_sub * 16 + tile * 4);
+        // residual rows of output component r (channel 16 kb + 4 c_sub + r), requested ahead of their use so that HBM
+        // latency hides behind the LDS exchange and the transform arithmetic
+        f4 rres[4][4];
+        auto rload = [&](int r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rres[r][i] = (res && n < batch) ? __builtin_nontemporal_load((const f4*)(res + plane0 + (size_t)r * 256 + (size_t)i * 64))
+                                                : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+        };
+        rload(0);
+        rload(1);
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            f2 other[18];                              // the partner's positions of MY tile block, components 2 round, 2 round + 1
+#pragma unroll
+            for (int q = 0; q < 18; ++q)
+                xch[(wave * 18 + q) * 64 + lane] = (f2){ acc[q][1 - HALF][2 * round], acc[q][1 - HALF][2 * round + 1] };
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 18; ++q) other[q] = xch[(partner * 18 + q) * 64 + lane];
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * round + rr;
+                __builtin_amdgcn_sched_barrier(0);     // keep one component's loads/stores from piling onto the next
+                float m[6][6];
+#pragma unroll
+                for (int p = 0; p < 18; ++p) {
+                    m[p / 6][p % 6] = HALF ? other[p][rr] : acc[p][0][r];
+                    m[(p + 18) / 6][(p + 18) % 6] = HALF ? acc[p][1][r] : other[p][rr];
+                }
+                float o[4][4];
+                inverse_transform(m, o);
+                const int k = 16 * kb + 4 * c_sub + r;
+                const float sc = scale[k], sh = shift[k];
+                if (n < batch) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f4 v;
+                        const f4 rv = rres[r][i];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = o[i][j] * sc + sh + rv[j];
+                            if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                            if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;   // cells off the board stay zero
+                        }
+                        __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
+                    }
+                }
+                if (r + 2 < 4) rload(r + 2);
+            }
+        }
+    };
+    if (half == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+}
+
+}  // namespace
+
+// x, y, res: activations in layout W (4096 floats per board; res may be null; y must not alias x); u: 36*64*64 pre-transformed
+// weights in A-operand order (torch_eval.cpp: wino_transform); scale/shift: [64].  Returns 0, or -1 when the board shape has
+// no kernel here.
+extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                float* y, int batch, int H, int W, int relu, void* stream) {
+    if (batch <= 0) return 0;
+    const dim3 grid((unsigned)((batch + NIMG - 1) / NIMG)), block(NTHR);
+    hipStream_t st = (hipStream_t)stream;
+    if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
+    else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
+    else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
+    else return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -19,8 +19,12 @@
 
 extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float* scale, const float* shift,
                                     int64_t numel, int channels, int hw, void* stream);
+extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                float* y, int batch, int H, int W, int relu, void* stream);
+extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                   int batch, int P, int H, int W, void* stream);
 extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const float* bias, float* out_p, float* out_v,
-                                       int64_t batch, int C, int HW, int PC, int VC, void* stream);
+                                       int64_t batch, int C, int HW, int PC, int VC, int board_w, void* stream);
 
 namespace {
 // The network of src/networks/grid_networks.py:30-79 with its parameters taken from the traced module, evaluated as
@@ -28,7 +32,8 @@ namespace {
 struct NativeNet {
     bool ok = false;
     at::Tensor stem_w, stem_scale, stem_shift;
-    struct Block { at::Tensor w1, s1, t1, w2, s2, t2; };
+    struct Block { at::Tensor w1, s1, t1, w2, s2, t2, u1, u2; };   // u*: Winograd-domain weights (cnn_wino.hip)
+    bool wino = false;              // every trunk convolution is 64 -> 64: the hand-written Winograd/MFMA kernel applies
     std::vector<Block> blocks;
     at::Tensor pconv_w, pconv_b, pfc_w, pfc_b, vconv_w, vconv_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b;
     at::Tensor heads_w, heads_b;     // [PC + VC][C] and [PC + VC]: both 1x1 head convolutions as one fused pass
@@ -52,6 +57,34 @@ bool fold_bn(const std::map<std::string, at::Tensor>& t, const std::string& conv
     scale = (g->second / at::sqrt(v->second + 1e-5)).contiguous();
     shift = ((B->second - m->second) * scale + b->second).contiguous();
     return true;
+}
+
+// U = G g G^T for F(4x4, 3x3), computed in double and stored in the lane order of the kernel's A operand:
+// U2[p = xi * 6 + nu][s][kb][lane] with output channel k = 16 kb + lane % 16, input channel = slot lane / 16 of group s.
+void wino_transform(const float* g, float* up) {
+    static const double G[6][3] = { { 1.0 / 4, 0, 0 },         { -1.0 / 6, -1.0 / 6, -1.0 / 6 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
+                                    { 1.0 / 24, 1.0 / 12, 1.0 / 6 }, { 1.0 / 24, -1.0 / 12, 1.0 / 6 }, { 0, 0, 1 } };
+    for (int k = 0; k < 64; ++k)
+        for (int c = 0; c < 64; ++c) {
+            const float* gk = g + ((size_t)k * 64 + c) * 9;
+            double t[6][3];
+            for (int a = 0; a < 6; ++a)
+                for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * gk[j] + G[a][1] * gk[3 + j] + G[a][2] * gk[6 + j];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+                    // K-loop step s reads group s of layout W: input channel c = 16 (s >> 2) + 4 slot + (s & 3)
+                    const int p = a * 6 + b, s = 4 * (c >> 4) + (c & 3), kb = k >> 4, lane = ((c >> 2) & 3) * 16 + (k & 15);
+                    up[(((size_t)p * 16 + s) * 4 + kb) * 64 + lane] = (float)v;
+                }
+        }
+}
+
+at::Tensor wino_weights(const at::Tensor& w_dev) {
+    at::Tensor w = w_dev.to(at::kCPU, at::kFloat).contiguous();
+    at::Tensor u = at::empty({ 36 * 64 * 64 }, at::TensorOptions().dtype(at::kFloat));
+    wino_transform(w.data_ptr<float>(), u.data_ptr<float>());
+    return u.to(w_dev.device());
 }
 
 void build_native(Model* m) {
@@ -85,6 +118,14 @@ void build_native(Model* m) {
     // every tensor of the traced module must be accounted for, otherwise this is not the architecture we know
     size_t expected = 6 + n.blocks.size() * 12 + 10 + (1 + 2 * n.blocks.size());   // + num_batches_tracked buffers
     if (t.size() != expected) return;
+    n.wino = !n.blocks.empty() && n.stem_w.size(0) == 64 && !getenv("SPRL_TORCH_NO_WINOGRAD");
+    for (const auto& b : n.blocks)
+        n.wino = n.wino && b.w1.size(0) == 64 && b.w1.size(1) == 64 && b.w2.size(0) == 64 && b.w2.size(1) == 64;
+    if (n.wino)
+        for (auto& b : n.blocks) {
+            b.u1 = wino_weights(b.w1);
+            b.u2 = wino_weights(b.w2);
+        }
     n.ok = true;
     m->native = n;
 }
@@ -95,23 +136,54 @@ bool epilogue(at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, c
                                 scale.data_ptr<float>(), shift.data_ptr<float>(), x.numel(), C, hw, nullptr) == 0;
 }
 
-bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value) {
-    at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
-    if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
-    for (const auto& b : n.blocks) {
-        at::Tensor y = at::conv2d(x, b.w1, {}, 1, 1);
-        if (!y.is_contiguous() || !epilogue(y, b.s1, b.t1, nullptr)) return false;
-        at::Tensor z = at::conv2d(y, b.w2, {}, 1, 1);
-        if (!z.is_contiguous() || !epilogue(z, b.s2, b.t2, &x)) return false;
-        x = z;
-    }
-    const int64_t B = x.size(0);
-    const int C = (int)x.size(1), HW = (int)(x.size(2) * x.size(3));
-    at::Tensor p = at::empty({ B, (int64_t)n.pc * HW }, x.options());
-    at::Tensor v = at::empty({ B, (int64_t)n.vc * HW }, x.options());
-    if (sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
-                                p.data_ptr<float>(), v.data_ptr<float>(), B, C, HW, n.pc, n.vc, nullptr) != 0)
+// Trunk entirely in hand-written kernels: stem (VALU) -> residual blocks (Winograd on fp32 MFMA, cnn_wino.hip) -> both
+// 1x1 heads, activations in layout W; only the three small fully connected layers go through the BLAS library.
+bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::Tensor& v) {
+    const int B = (int)in.size(0), P = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3);
+    auto opts = in.options();
+    at::Tensor x = at::empty({ B, 4096 }, opts), y = at::empty({ B, 4096 }, opts), z = at::empty({ B, 4096 }, opts);
+    if (sprl_stem_conv3x3_w(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
+                            n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, nullptr) != 0)
         return false;
+    for (const auto& b : n.blocks) {
+        if (sprl_wino_conv64(x.data_ptr<float>(), b.u1.data_ptr<float>(), b.s1.data_ptr<float>(), b.t1.data_ptr<float>(), nullptr,
+                             y.data_ptr<float>(), B, H, W, 1, nullptr) != 0 ||
+            sprl_wino_conv64(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(), b.t2.data_ptr<float>(),
+                             x.data_ptr<float>(), z.data_ptr<float>(), B, H, W, 1, nullptr) != 0)
+            return false;
+        std::swap(x, z);
+    }
+    const int HW = H * W;
+    p = at::empty({ B, (int64_t)n.pc * HW }, opts);
+    v = at::empty({ B, (int64_t)n.vc * HW }, opts);
+    return sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
+                                   p.data_ptr<float>(), v.data_ptr<float>(), B, 64, HW, n.pc, n.vc, W, nullptr) == 0;
+}
+
+bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value) {
+    at::Tensor p, v;
+    const int H0 = (int)in.size(2), W0 = (int)in.size(3), P0 = (int)in.size(1);
+    const bool wino = n.wino && (P0 == 3 || P0 == 17) && ((H0 == 8 && W0 == 8) || (H0 == 6 && W0 == 7) || (H0 == 7 && W0 == 7));
+    if (wino) {
+        if (!forward_wino(n, in, p, v)) return false;
+    } else {
+        at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
+        if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
+        for (const auto& b : n.blocks) {
+            at::Tensor y = at::conv2d(x, b.w1, {}, 1, 1);
+            if (!y.is_contiguous() || !epilogue(y, b.s1, b.t1, nullptr)) return false;
+            at::Tensor z = at::conv2d(y, b.w2, {}, 1, 1);
+            if (!z.is_contiguous() || !epilogue(z, b.s2, b.t2, &x)) return false;
+            x = z;
+        }
+        const int64_t B = x.size(0);
+        const int C = (int)x.size(1), HW = (int)(x.size(2) * x.size(3));
+        p = at::empty({ B, (int64_t)n.pc * HW }, x.options());
+        v = at::empty({ B, (int64_t)n.vc * HW }, x.options());
+        if (sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
+                                    p.data_ptr<float>(), v.data_ptr<float>(), B, C, HW, n.pc, n.vc, 0, nullptr) != 0)
+            return false;
+    }
     logits = at::addmm(n.pfc_b, p, n.pfc_w);
     v = at::relu(at::addmm(n.vfc1_b, v, n.vfc1_w));
     value = at::tanh(at::addmm(n.vfc2_b, v, n.vfc2_w));
@@ -220,6 +292,9 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
         return -1;
     }
 }
+
+// host -> host: conv weight [64][64][3][3] to the Winograd-domain layout sprl_wino_conv64 takes (36*64*64 floats)
+void sprl_wino_transform_weights(const float* w, float* u) { wino_transform(w, u); }
 
 void sprl_torch_free(void* handle) { delete static_cast<Model*>(handle); }
 

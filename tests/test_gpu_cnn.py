@@ -1,0 +1,93 @@
+"""The hand-written trunk convolution (sprl_amd/csrc/cnn_wino.hip: Winograd F(4x4,3x3) on fp32 MFMA with fused
+scale/shift/residual/ReLU) against PyTorch's fp32 conv2d on the same inputs.  Tolerance: 2e-4 absolute on outputs of
+magnitude O(1-10) — F(4x4,3x3) in fp32 carries ~1e-5 relative error through its transforms."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from sprl_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def plug():
+    E.load_library()
+    p = C.CDLL(os.path.join(os.path.dirname(E.DEFAULT_LIB), "libsprl_amd_torch.so"))
+    p.sprl_wino_conv64.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
+    p.sprl_wino_transform_weights.argtypes = [C.c_void_p, C.c_void_p]
+    return p
+
+
+def to_w(x):
+    """NCHW [n][64][H][W] -> layout W [n][g][i][cs][tile][j] (4096 floats per board, zeros off the board)."""
+    import torch
+    n, _, H, W = x.shape
+    p = torch.zeros(n, 64, 8, 8, device=x.device, dtype=x.dtype)
+    p[:, :, :H, :W] = x
+    p = p.reshape(n, 4, 4, 4, 2, 4, 2, 4)            # n, kb, cs, kr, ty, i, tx, j   (k = 16 kb + 4 cs + kr)
+    return p.permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous().reshape(n, 4096)
+
+
+def from_w(y, H, W):
+    n = y.shape[0]
+    p = y.reshape(n, 4, 4, 4, 4, 2, 2, 4)            # n, kb, kr, i, cs, ty, tx, j
+    p = p.permute(0, 1, 4, 2, 5, 3, 6, 7).contiguous().reshape(n, 64, 8, 8)
+    assert (p[:, :, H:, :] == 0).all() and (p[:, :, :, W:] == 0).all(), "cells off the board must be zero"
+    return p[:, :, :H, :W]
+
+
+def run_conv(plug, x, w, scale, shift, res, relu):
+    import torch
+    u = np.zeros(36 * 64 * 64, np.float32)
+    wc = np.ascontiguousarray(w.cpu().numpy())
+    plug.sprl_wino_transform_weights(wc.ctypes.data, u.ctypes.data)
+    ud = torch.from_numpy(u).cuda()
+    B, _, H, W = x.shape
+    xw = to_w(x)
+    rw = to_w(res) if res is not None else None
+    yw = torch.full_like(xw, float("nan"))
+    rc = plug.sprl_wino_conv64(xw.data_ptr(), ud.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                               rw.data_ptr() if rw is not None else None, yw.data_ptr(), B, H, W, int(relu), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return from_w(yw, H, W)
+
+
+@pytest.mark.parametrize("H,W,B", [(8, 8, 8), (8, 8, 13), (8, 8, 1024), (6, 7, 37), (7, 7, 64), (8, 8, 1)])
+def test_wino_conv_matches_conv2d(plug, H, W, B):
+    import torch
+    torch.manual_seed(H * 100 + W * 10 + B)
+    x = torch.randn(B, 64, H, W, device="cuda")
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.06
+    scale = torch.rand(64, device="cuda") + 0.5
+    shift = torch.randn(64, device="cuda") * 0.3
+    res = torch.randn(B, 64, H, W, device="cuda")
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    for use_res, relu in ((False, True), (True, True), (False, False)):
+        want = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        if use_res:
+            want = want + res.double()
+        if relu:
+            want = torch.relu(want)
+        got = run_conv(plug, x, w, scale, shift, res if use_res else None, relu)
+        err = (got.double() - want).abs().max().item()
+        assert err < 2e-4, (H, W, B, use_res, relu, err)
+
+
+def test_wino_structured_inputs(plug):
+    """One-hot inputs and one-hot filters: every (tap, border) combination lands where conv2d puts it."""
+    import torch
+    x = torch.zeros(9, 64, 8, 8, device="cuda")
+    w = torch.zeros(64, 64, 3, 3, device="cuda")
+    for n in range(9):
+        x[n, (7 * n) % 64, (3 * n) % 8, (5 * n + 1) % 8] = 1.0 + n
+    for k in range(64):
+        w[k, (k * 5) % 64, k % 3, (k // 3) % 3] = 1.0
+        w[k, (k * 11 + 1) % 64, (k + 1) % 3, (k // 5) % 3] = -0.5
+    one, zero = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    got = run_conv(plug, x, w, one, zero, None, False)
+    want = torch.nn.functional.conv2d(x, w, padding=1)
+    assert (got - want).abs().max().item() < 1e-5

@@ -139,11 +139,17 @@ def test_torchscript_cnn_through_libtorch(lib, traced_model):
     np.testing.assert_allclose(vg.cpu().numpy(), vc.numpy(), atol=1e-4, rtol=0)
 
 
-def test_native_cnn_path_matches_torchscript(lib, traced_model):
-    """The plugin's recognised-architecture path (MIOpen convs + hand-written fused bias/BN/ReLU(/residual) epilogue)
-    against the plain TorchScript forward of the same file: 2e-5 abs on logits and value."""
+@pytest.mark.parametrize("game", ["othello", "connect_four", "go7"])
+def test_native_cnn_path_matches_torchscript(lib, game, tmp_path):
+    """The plugin's recognised-architecture path — stem kernel, Winograd F(4x4,3x3) trunk on fp32 MFMA with fused
+    BN/residual/ReLU, fused 1x1 heads (cnn_wino.hip, cnn_epilogue.hip) — against the plain TorchScript fp32 forward of the
+    same file: 1e-4 absolute on logits and value (the Winograd transforms carry ~1e-5 relative error per layer)."""
     import ctypes as C
     import torch
+    from sprl_amd.network import GAME_SHAPES, make_network, trace_to_file
+    model = trace_to_file(make_network(game, 2, 64, seed=1), str(tmp_path / f"traced_{game}.pt"), game)
+    rows, cols, actions, hist = GAME_SHAPES[game]
+    planes = 2 * hist + 1
     plug = C.CDLL(os.path.join(os.path.dirname(E.DEFAULT_LIB), "libsprl_amd_torch.so"))
     plug.sprl_torch_load.restype = C.c_void_p
     plug.sprl_torch_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
@@ -151,20 +157,20 @@ def test_native_cnn_path_matches_torchscript(lib, traced_model):
                                                                                  C.c_char_p, C.c_int]
     plug.sprl_torch_is_native.argtypes = [C.c_void_p]
     err = C.create_string_buffer(512)
-    h = plug.sprl_torch_load(traced_model.encode(), 0, err, 512)
+    h = plug.sprl_torch_load(model.encode(), 0, err, 512)
     assert h, err.value
     assert plug.sprl_torch_is_native(h) == 1
-    ref = torch.jit.load(traced_model, map_location="cuda").eval()
-    for batch in (3, 1024, 4096):
-        x = (torch.rand(batch, 3, 8, 8, device="cuda") > 0.6).float().contiguous()
-        lo = torch.zeros(batch, 65, device="cuda")
+    ref = torch.jit.load(model, map_location="cuda").eval()
+    for batch in (3, 1024, 4099):
+        x = (torch.rand(batch, planes, rows, cols, device="cuda") > 0.6).float().contiguous()
+        lo = torch.zeros(batch, actions, device="cuda")
         va = torch.zeros(batch, device="cuda")
-        assert plug.sprl_torch_forward(h, x.data_ptr(), batch, 3, 8, 8, lo.data_ptr(), 65, va.data_ptr(), err, 512) == 0, err.value
+        assert plug.sprl_torch_forward(h, x.data_ptr(), batch, planes, rows, cols, lo.data_ptr(), actions, va.data_ptr(), err, 512) == 0, err.value
         torch.cuda.synchronize()
         with torch.no_grad():
             rl, rv = ref(x)
-        np.testing.assert_allclose(lo.cpu().numpy(), rl.cpu().numpy(), atol=2e-5, rtol=0)
-        np.testing.assert_allclose(va.cpu().numpy(), rv.cpu().numpy().reshape(-1), atol=2e-5, rtol=0)
+        np.testing.assert_allclose(lo.cpu().numpy(), rl.cpu().numpy(), atol=1e-4, rtol=0)
+        np.testing.assert_allclose(va.cpu().numpy(), rv.cpu().numpy().reshape(-1), atol=1e-4, rtol=0)
 
 
 def test_full_size_properties(lib):
