@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
 
     // chunk = groups 2c, 2c+1 of 8 boards: 1024 float4, two per thread.  float4 f of a board's chunk:
     // f = ((gl * 4 + i) * 4 + cs) * 4 + tile  ->  channel slot gl * 4 + cs, row 4 ty + i, columns 4 tx .. 4 tx + 3
-    f4 pre[2][2];                                     // two register sets: a chunk's loads get 1.5 phases to land
+    f4 pre[2];                                        // one chunk in flight from HBM (a full phase to land)
     int ldst[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
         const int gl = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
         ldst[it] = (gl * 4 + cs) * CS + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
     }
-    auto gload = [&](int chunk, f4 (&pre)[2]) {
+    auto gload = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int f = tid + NTHR * it;
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
                                   : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
         }
     };
-    auto lstore = [&](float* buf, const f4 (&pre)[2]) {
+    auto lstore = [&](float* buf) {
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -163,66 +163,78 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
     const float* ua = u + (size_t)(18 * half) * (16 * 4 * 64) + kb * 64 + lane;
     const float* vsrc = v_buf + (18 * half) * 128 + lane;
 
-    // weights and MFMAs of one chunk (two groups) for this wave, in six slices of six transform positions; the weight
-    // loads run three slices (18 registers) ahead of the MFMAs that use them
-    auto aload = [&](int c, int k, float (&a)[6]) {
+    // weights and MFMAs of one chunk (two groups) for this wave, in six slices of six transform positions.  The weights
+    // live in a 36-register ring that runs one whole chunk ahead: as soon as a slice's MFMAs are issued its registers are
+    // reloaded with the same slice of the next chunk (~1 us of MFMA work covers an L2 miss).
+    float a[6][6];
+    auto aload = [&](int c, int k) {
         const int s = 2 * c + k / 3, q0 = (k % 3) * 6;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) a[q] = (ABL & 4) ? (float)(q + s) : ua[(size_t)(q0 + q) * (16 * 4 * 64) + s * 256];
+        for (int q = 0; q < 6; ++q) a[k][q] = (ABL & 4) ? (float)(q + s) : ua[(size_t)(q0 + q) * (16 * 4 * 64) + s * 256];
     };
-    auto mma = [&](const float* vs, int k, const float (&a)[6]) {
+    auto mma = [&](const float* vs, int k) {
         const float* vk = vs + (k / 3) * V_BUF + (k % 3) * 6 * 128;
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const float b0 = vk[q * 128], b1 = vk[q * 128 + 64];
             const int qq = (k % 3) * 6 + q;
             if (ABL & 8) {
-                acc[qq][0][0] += a[q] * b0;
-                acc[qq][1][0] += a[q] * b1;
+                acc[qq][0][0] += a[k][q] * b0;
+                acc[qq][1][0] += a[k][q] * b1;
             } else {
-                acc[qq][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b0, acc[qq][0], 0, 0, 0);
-                acc[qq][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b1, acc[qq][1], 0, 0, 0);
+                acc[qq][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b0, acc[qq][0], 0, 0, 0);
+                acc[qq][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b1, acc[qq][1], 0, 0, 0);
             }
         }
     };
-    // phase c: MFMAs on V(c) while V(c+1) is built; chunk c+2 goes to LDS, chunk c+4 is requested from HBM.
-    // Memory-counter order matters (vmcnt retires in order): the HBM request is issued AFTER the weight loads, so waiting
-    // for the weights never waits for HBM.  The two waves of a SIMD (half 0 / half 1) run produce and MFMA in opposite
-    // order, so one does VALU/LDS work while the other feeds the matrix core.
-    auto phase = [&](int c, f4 (&pset)[2]) {
-        if (c + 2 < 8) lstore(in_buf + (c & 1) * IN_BUF, pset);          // in_buf[c & 1]: V(c) was built in phase c - 1
+    // phase c: MFMAs on V(c) while V(c+1) is built; at its end chunk c+2 goes to LDS and chunk c+3 is requested from HBM.
+    // Memory-counter order matters (vmcnt retires in order): every weight load is consumed a whole phase after it was
+    // issued and the HBM request a whole phase after it was issued, so no wait ever lands on a young HBM request.
+    // The two waves of a SIMD (half 0 / half 1) run produce and MFMA in opposite order, so one does VALU/LDS work while
+    // the other feeds the matrix core.
+    auto phase = [&](int c) {
         const float* vs = vsrc + (c & 1) * 2 * V_BUF;
         if (half == 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
         __builtin_amdgcn_sched_barrier(0);
-        float a[3][6];
-        aload(c, 0, a[0]);
-        aload(c, 1, a[1]);
-        aload(c, 2, a[2]);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            mma(vs, k, a[k % 3]);
-            if (k + 3 < 6) aload(c, k + 3, a[k % 3]);
-            if (k == 2 && c + 4 < 8) gload(c + 4, pset);     // after the chunk's last weight request (vmcnt order)
+            mma(vs, k);
+            if (c + 1 < 8) aload(c + 1, k);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (half != 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
+        if (c + 2 < 8) {
+            lstore(in_buf + (c & 1) * IN_BUF);         // in_buf[c & 1]: V(c) was built in phase c - 1
+            if (c + 3 < 8) gload(c + 3);
+        }
         __syncthreads();
     };
 
-    gload(0, pre[0]);
-    gload(1, pre[1]);
+    // residual rows of output component r (channel 16 kb + 4 c_sub + r) of this lane's tile: requested two components ahead of
+    // their use (the first two before the LDS exchange), so that HBM latency hides behind LDS traffic and arithmetic
+    const int t_out = 16 * half + tl;                 // tile this lane finishes
+    const int n = n0 + (t_out >> 2), tile = t_out & 3;
+    const size_t plane0 = (size_t)n * 4096 + (size_t)(4 * kb) * 256 + (size_t)(c_sub * 16 + tile * 4);
+    f4 rres[4][4];
+    auto rload = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rres[r][i] = (res && n < batch) ? __builtin_nontemporal_load((const f4*)(res + plane0 + (size_t)r * 256 + (size_t)i * 64))
+                                            : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    };
+
+    gload(0);
     __syncthreads();                                   // zero fill done
-    lstore(in_buf, pre[0]);
-    lstore(in_buf + IN_BUF, pre[1]);
-    gload(2, pre[0]);
-    gload(3, pre[1]);
+    lstore(in_buf);
+    gload(1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) aload(0, k);
+    lstore(in_buf + IN_BUF);
+    gload(2);
     __syncthreads();
     produce(0);
     __syncthreads();
-    for (int c = 0; c < 8; c += 2) {
-        phase(c, pre[0]);
-        phase(c + 1, pre[1]);
-    }
+    for (int c = 0; c < 8; ++c) phase(c);
 
     if (ABL & 1) {
         float sum = 0.0f;
@@ -239,18 +251,7 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
     const int partner = wave ^ 4;
     auto finish = [&](auto half_c) {
         constexpr int HALF = decltype(half_c)::value;
-        const int t = 16 * HALF + tl;                  // tile of this lane
-        const int n = n0 + (t >> 2), tile = t & 3, ty = tile >> 1, tx = tile & 1;
-        const size_t plane0 = (size_t)n * 4096 + (size_t)(4 * kb) * 256 + (size_t)(c_sub * 16 + tile * 4);
-        // residual rows of output component r (channel 16 kb + 4 c_sub + r), requested ahead of their use so that HBM
-        // latency hides behind the LDS exchange and the transform arithmetic
-        f4 rres[4][4];
-        auto rload = [&](int r) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rres[r][i] = (res && n < batch) ? __builtin_nontemporal_load((const f4*)(res + plane0 + (size_t)r * 256 + (size_t)i * 64))
-                                                : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
-        };
+        const int ty = tile >> 1, tx = tile & 1;
         rload(0);
         rload(1);
 #pragma unroll

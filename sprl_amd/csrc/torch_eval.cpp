@@ -298,8 +298,11 @@ void sprl_wino_transform_weights(const float* w, float* u) { wino_transform(w, u
 
 void sprl_torch_free(void* handle) { delete static_cast<Model*>(handle); }
 
-// 1 when the network was recognised and runs as MIOpen convolutions + the hand-written fused epilogue kernel,
-// 0 when it runs as the generic (rewritten) TorchScript graph
-int sprl_torch_is_native(void* handle) { return static_cast<Model*>(handle)->native.ok ? 1 : 0; }
+// 2: recognised architecture with a 64-channel trunk — stem, Winograd/MFMA trunk and heads all in the hand-written kernels;
+// 1: recognised, convolutions in MIOpen + the hand-written fused epilogue; 0: generic (rewritten) TorchScript graph
+int sprl_torch_is_native(void* handle) {
+    const NativeNet& n = static_cast<Model*>(handle)->native;
+    return n.ok ? (n.wino ? 2 : 1) : 0;
+}
 
 }  // extern "C"

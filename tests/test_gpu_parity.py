@@ -159,7 +159,7 @@ def test_native_cnn_path_matches_torchscript(lib, game, tmp_path):
     err = C.create_string_buffer(512)
     h = plug.sprl_torch_load(model.encode(), 0, err, 512)
     assert h, err.value
-    assert plug.sprl_torch_is_native(h) == 1
+    assert plug.sprl_torch_is_native(h) == 2
     ref = torch.jit.load(model, map_location="cuda").eval()
     for batch in (3, 1024, 4099):
         x = (torch.rand(batch, planes, rows, cols, device="cuda") > 0.6).float().contiguous()
