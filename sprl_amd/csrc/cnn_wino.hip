@@ -28,6 +28,7 @@
 // 16-byte stores that are contiguous over 16 lanes (256-byte rows of layout W).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -300,7 +301,209 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
     else finish(std::integral_constant<int, 1>{});
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Version 2: 4 waves = 4 boards = 16 tiles per workgroup, TWO workgroups per CU.
+// Wave kb owns output channels 16kb..16kb+15 for ALL 36 transform positions of the 16 tiles (36 accumulator tiles,
+// 144 registers), so a lane ends the K loop holding every position of its four (channel, tile) pairs and the inverse
+// transform needs no exchange.  The two resident workgroups of a CU run half a period apart (the second one of the first
+// round sleeps once), so the prologue / output stage of one overlaps the MFMA phases of the other, and so does their HBM
+// traffic.  Same LDS images, V production, weight layout and activation layout as above.
+// ---------------------------------------------------------------------------------------------------
+constexpr int NIMG2 = 4, NTHR2 = 256;
+constexpr int CS2 = 449;                 // channel-slot stride for 4 boards (== 1 mod 32)
+constexpr int IN_BUF2 = 8 * CS2;
+constexpr int V_G2 = 36 * 64;            // V of one group: [p][c_sub][16 tiles]
+constexpr int LDS_FLOATS2 = 2 * IN_BUF2 + 4 * V_G2;      // 65.6 KB
+
+template <int H, int W, int ABL = 0>
+__global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ res, float* __restrict__ y, int batch,
+                                                                  int relu, int stagger) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS2];
+    float* const in_buf = lds;                        // [2][IN_BUF2]
+    float* const v_buf = lds + 2 * IN_BUF2;           // [2 phases][2 groups][V_G2]
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c_sub = lane >> 4, tl = lane & 15;
+    const int n0 = (int)blockIdx.x * NIMG2;
+    const int gl = wave & 1, wa = wave >> 1;          // producer role: group of the chunk, transform rows 3wa..3wa+2
+    const int kb = wave;                              // consumer role: output channels 16kb..16kb+15
+
+    for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;    // borders stay zero for the whole kernel
+
+    // first round only: the workgroup in the second wave slot of its SIMD starts half a period late
+    if (stagger > 0 && (int)blockIdx.x < 2 * 256) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID.WAVE_ID
+        if (slot & 1u)
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    f4 acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    f4 pre[2];
+    int ldst[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int f = tid + NTHR2 * it;
+        const int b = f >> 7, rem = f & 127;
+        const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
+        ldst[it] = (g2 * 4 + cs) * CS2 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
+    }
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int f = tid + NTHR2 * it;
+            const int n = n0 + (f >> 7);
+            pre[it] = (ABL & 16) ? (f4){ 1.0f, 1.0f, 1.0f, 1.0f }
+                      : n < batch ? __builtin_nontemporal_load((const f4*)(x + (size_t)n * 4096 + (size_t)chunk * 512 + (size_t)(f & 127) * 4))
+                                  : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+        }
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = pre[it][j];
+    };
+    const int patch0 = (gl * 4 + c_sub) * CS2 + board_off(tl >> 2) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
+    const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
+    auto produce = [&](int c) {
+        const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
+        float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
+        float wr[3][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
+            const float st = 4.0f * e0 - 5.0f * e2 + e4;
+            if (wa == 0) {
+                const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                wr[0][j] = st;
+                wr[1][j] = p + q;
+                wr[2][j] = p - q;
+            } else {
+                const float p = e3 - e1, q = 2.0f * (e2 - e0);
+                wr[0][j] = p + q;
+                wr[1][j] = p - q;
+                wr[2][j] = st;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+            const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
+            vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
+            vd[(r * 6 + 1) * 64] = p + q;
+            vd[(r * 6 + 2) * 64] = p - q;
+            vd[(r * 6 + 3) * 64] = p2 + q2;
+            vd[(r * 6 + 4) * 64] = p2 - q2;
+            vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
+        }
+    };
+    // A operand: U4[p / 4][s][kb][lane][p % 4] (16-byte loads, four transform positions each); a 36-register ring that
+    // runs one group (36 MFMAs) ahead
+    const f4* ua = (const f4*)u + kb * 64 + lane;
+    f4 a[9];
+    auto aload = [&](int s, int k) {
+        a[k] = (ABL & 4) ? (f4){ (float)s, 1.0f, 2.0f, (float)k } : ua[(size_t)k * (16 * 4 * 64) + s * 256];
+    };
+    auto mma = [&](const float* vg, int k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float b = vg[(k * 4 + q) * 64 + lane];
+            if (ABL & 8) acc[k * 4 + q][0] += a[k][q] * b;
+            else acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
+        }
+    };
+    auto phase = [&](int c) {
+        const float* vs = v_buf + (c & 1) * 2 * V_G2;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int s = 2 * c + g2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                mma(vs + g2 * V_G2, k);
+                if (s + 1 < 16) aload(s + 1, k);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < 8 && !(ABL & 2)) produce(c + 1);
+        if (c + 2 < 8) {
+            lstore(in_buf + (c & 1) * IN_BUF2);        // in_buf[c & 1]: V(c) was built in phase c - 1
+            if (c + 3 < 8) gload(c + 3);
+        }
+        __syncthreads();
+    };
+
+    const int n = n0 + (tl >> 2), tile = tl & 3;      // this lane's tile
+    const size_t plane0 = (size_t)n * 4096 + (size_t)(4 * kb) * 256 + (size_t)(c_sub * 16 + tile * 4);
+    f4 rres[4][4];
+    auto rload = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rres[r][i] = (res && n < batch) ? __builtin_nontemporal_load((const f4*)(res + plane0 + (size_t)r * 256 + (size_t)i * 64))
+                                            : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    };
+
+    gload(0);
+    __syncthreads();                                   // zero fill done
+    lstore(in_buf);
+    gload(1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aload(0, k);
+    lstore(in_buf + IN_BUF2);
+    gload(2);
+    __syncthreads();
+    produce(0);
+    __syncthreads();
+    for (int c = 0; c < 8; ++c) phase(c);
+
+    if (ABL & 1) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 36; ++q) sum += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+        if (sum == 123.456f) y[tid] = sum;
+        return;
+    }
+
+    // ---- inverse transform in registers + epilogue ----
+    const int ty = tile >> 1, tx = tile & 1;
+    rload(0);
+    rload(1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        float m[6][6];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = acc[p][r];
+        float o[4][4];
+        inverse_transform(m, o);
+        const int k = 16 * kb + 4 * c_sub + r;
+        const float sc = scale[k], sh = shift[k];
+        if (n < batch) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f4 v;
+                const f4 rv = rres[r][i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = o[i][j] * sc + sh + rv[j];
+                    if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                    if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;       // cells off the board stay zero
+                }
+                __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
+            }
+        }
+        if (r + 2 < 4) rload(r + 2);
+    }
+}
+
 }  // namespace
+
+// sprl_wino_weight_layout(): 1 = U2[p][s][kb][lane], 2 = U4[p / 4][s][kb][lane][p % 4] (what wino_transform must produce)
+extern "C" int sprl_wino_weight_layout(void) { return getenv("SPRL_WINO_V1") ? 1 : 2; }
 
 // x, y, res: activations in layout W (4096 floats per board; res may be null; y must not alias x); u: 36*64*64 pre-transformed
 // weights in A-operand order (torch_eval.cpp: wino_transform); scale/shift: [64].  Returns 0, or -1 when the board shape has
@@ -308,8 +511,18 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
 extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                 float* y, int batch, int H, int W, int relu, void* stream) {
     if (batch <= 0) return 0;
-    const dim3 grid((unsigned)((batch + NIMG - 1) / NIMG)), block(NTHR);
     hipStream_t st = (hipStream_t)stream;
+    static const int version = getenv("SPRL_WINO_V1") ? 1 : 2;
+    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
+    if (version == 2) {
+        const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
+        if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger);
+        else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger);
+        else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger);
+        else return -1;
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    const dim3 grid((unsigned)((batch + NIMG - 1) / NIMG)), block(NTHR);
     if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
     else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
     else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);

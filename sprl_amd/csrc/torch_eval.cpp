@@ -21,6 +21,7 @@ extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float
                                     int64_t numel, int channels, int hw, void* stream);
 extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                 float* y, int batch, int H, int W, int relu, void* stream);
+extern "C" int sprl_wino_weight_layout(void);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, void* stream);
 extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const float* bias, float* out_p, float* out_v,
@@ -62,6 +63,7 @@ bool fold_bn(const std::map<std::string, at::Tensor>& t, const std::string& conv
 // U = G g G^T for F(4x4, 3x3), computed in double and stored in the lane order of the kernel's A operand:
 // U2[p = xi * 6 + nu][s][kb][lane] with output channel k = 16 kb + lane % 16, input channel = slot lane / 16 of group s.
 void wino_transform(const float* g, float* up) {
+    const bool packed4 = sprl_wino_weight_layout() == 2;       // U4[p / 4][s][kb][lane][p % 4] instead of U2[p][s][kb][lane]
     static const double G[6][3] = { { 1.0 / 4, 0, 0 },         { -1.0 / 6, -1.0 / 6, -1.0 / 6 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
                                     { 1.0 / 24, 1.0 / 12, 1.0 / 6 }, { 1.0 / 24, -1.0 / 12, 1.0 / 6 }, { 0, 0, 1 } };
     for (int k = 0; k < 64; ++k)
@@ -75,7 +77,8 @@ void wino_transform(const float* g, float* up) {
                     const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
                     // K-loop step s reads group s of layout W: input channel c = 16 (s >> 2) + 4 slot + (s & 3)
                     const int p = a * 6 + b, s = 4 * (c >> 4) + (c & 3), kb = k >> 4, lane = ((c >> 2) & 3) * 16 + (k & 15);
-                    up[(((size_t)p * 16 + s) * 4 + kb) * 64 + lane] = (float)v;
+                    if (packed4) up[((((size_t)(p >> 2) * 16 + s) * 4 + kb) * 64 + lane) * 4 + (p & 3)] = (float)v;
+                    else up[(((size_t)p * 16 + s) * 4 + kb) * 64 + lane] = (float)v;
                 }
         }
 }

@@ -21,6 +21,22 @@ static float run(const float* x, const float* u, const float* sc, const float* s
     return ms * 1000.0f / iters;
 }
 
+template <int ABL>
+static float run2(const float* x, const float* u, const float* sc, const float* sh, const float* res, float* y, int B, int iters, int stagger) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    dim3 grid((B + NIMG2 - 1) / NIMG2), block(NTHR2);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms * 1000.0f / iters;
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 16384;
     float *x, *y, *r, *u, *sc, *sh;
@@ -35,6 +51,12 @@ int main(int argc, char** argv) {
     hipMemcpy(sc, h.data(), 256, hipMemcpyHostToDevice);
     hipMemcpy(sh, h.data(), 256, hipMemcpyHostToDevice);
     printf("batch %d, us per launch\n", B);
+    for (int sg = 0; sg <= 8; sg += 2) printf("v2 full, stagger %d            %8.1f\n", sg, run2<0>(x, u, sc, sh, r, y, B, 20, sg));
+    printf("v2 no output stage           %8.1f\n", run2<1>(x, u, sc, sh, r, y, B, 20, 4));
+    printf("v2 no V production           %8.1f\n", run2<2>(x, u, sc, sh, r, y, B, 20, 4));
+    printf("v2 no weight loads           %8.1f\n", run2<4>(x, u, sc, sh, r, y, B, 20, 4));
+    printf("v2 no output, no V, no wts   %8.1f\n", run2<7>(x, u, sc, sh, r, y, B, 20, 4));
+    printf("v2 skeleton + MFMA           %8.1f\n", run2<23>(x, u, sc, sh, r, y, B, 20, 4));
     printf("full                         %8.1f\n", run<0>(x, u, sc, sh, r, y, B, 20));
     printf("no output stage              %8.1f\n", run<1>(x, u, sc, sh, r, y, B, 20));
     printf("no V production              %8.1f\n", run<2>(x, u, sc, sh, r, y, B, 20));
