@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+MFMA_F32_PEAK_TF = 157.3            # dense fp32 matrix peak, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+WINO_FLOP_PER_BOARD = 2 * 4 * 36 * 64 * 64
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -251,12 +253,33 @@ def main():
             if os.path.exists(tpath):           # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
                 with open(tpath) as tf:
                     traffic = json.load(tf).get("hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "kernel": "step_kernel<Othello> (select/expand/backup/re-root)",
-                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "bytes_per_traversal": bpt,
-                               "avg_launch_ms": d["kernel_ms"] / max(1, d["kernel_launches"]),
-                               "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"])}
+            tree = {"bound": "hbm", "kernel": "step_kernel<Othello> (select/expand/backup/re-root)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "bytes_per_traversal": bpt,
+                    "avg_launch_ms": d["kernel_ms"] / max(1, d["kernel_launches"]),
+                    "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"])}
+            if d.get("conv_ms", 0) > 0:
+                # the dominant kernel by time: the trunk convolution of the CNN (cnn_wino.hip), fp32 MFMA-bound.
+                # Algorithmic work per board and launch = the Winograd-domain products the kernel must issue:
+                # 4 tiles x 36 positions x 64 x 64 multiply-adds (4x fewer than the direct 3x3 convolution).
+                flop = d["conv_boards"] * WINO_FLOP_PER_BOARD
+                tf = flop / (d["conv_ms"] * 1e-3) / 1e12
+                ctraffic = None
+                cpath = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
+                if os.path.exists(cpath):
+                    with open(cpath) as tf_:
+                        ctraffic = json.load(tf_).get("hbm_bytes_per_launch")
+                out["roofline"] = {"bound": "mfma", "kernel": "wino_conv64_v2_kernel<8,8> (3x3 conv 64->64 + BN/residual/ReLU, fp32)",
+                                   "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                                   "traffic": ctraffic, "share_of_step_time": d["conv_ms"] * 1e-3 / elapsed,
+                                   "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
+                                   "boards_per_launch": d["conv_boards"] / max(1, d["conv_launches"]),
+                                   "flop_per_board": WINO_FLOP_PER_BOARD,
+                                   "direct_conv_equivalent_tflops": tf * 4.0}
+                out["roofline_tree"] = tree
+            else:
+                out["roofline"] = tree
         if world == 1 and not args.no_cpu_baseline:
             mp_model = model_path
             if mp_model is None:

@@ -144,6 +144,9 @@ typedef struct sprl_stats {
     /* shader-clock cycles summed over game slots, per phase; 0 unless built with -DSPRL_PHASE_TIMERS (diagnosis) */
     int64_t cyc_total, cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise,
         cyc_max_slot_launch, cyc_lvl_wait, cyc_lvl_pick, cyc_lvl_desc;
+    /* trunk-convolution kernel of the hand-written CNN (HIP events around every launch; profile=1) */
+    double conv_ms;
+    int64_t conv_launches, conv_boards;
 } sprl_stats;
 int sprl_engine_stats(sprl_engine* e, sprl_stats* out);
 

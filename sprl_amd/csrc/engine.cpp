@@ -79,6 +79,8 @@ struct TorchPlugin {
     int (*forward)(void*, const float*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
     void (*release)(void*) = nullptr;
     int (*is_native)(void*) = nullptr;
+    void (*profile_enable)(void*, int) = nullptr;
+    void (*profile_read)(void*, double*, int64_t*, int64_t*) = nullptr;
 };
 
 struct RecordsOwner {
@@ -152,6 +154,8 @@ int load_torch_plugin(sprl_engine* e) {
     e->torch.forward = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, char*, int))dlsym(lib, "sprl_torch_forward");
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
     e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
+    e->torch.profile_enable = (void (*)(void*, int))dlsym(lib, "sprl_torch_profile_enable");
+    e->torch.profile_read = (void (*)(void*, double*, int64_t*, int64_t*))dlsym(lib, "sprl_torch_profile_read");
     if (!e->torch.load || !e->torch.forward || !e->torch.release)
         return fail(SPRL_E_MODEL, "LibTorch evaluator plugin lacks required symbols");
     return 0;
@@ -336,6 +340,7 @@ int sprl_engine_set_model(sprl_engine* e, const char* model) {
     if (rc) return rc;
     if (e->torch_model) e->torch.release(e->torch_model);
     e->torch_model = m;
+    if (e->cfg.profile && e->torch.profile_enable) e->torch.profile_enable(m, 1);
     e->forward_cb = nullptr;
     e->eval_kind = SPRL_EVAL_NETWORK;
     return 0;
@@ -730,6 +735,8 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
     out->kernel_ms = e->kernel_ms;
     out->nn_ms = e->nn_ms;
     out->hbm_bytes = (int64_t)e->hbm_bytes;
+    if (e->torch_model && e->torch.profile_read && e->cfg.profile)
+        e->torch.profile_read(e->torch_model, &out->conv_ms, &out->conv_launches, &out->conv_boards);
     return 0;
 }
 

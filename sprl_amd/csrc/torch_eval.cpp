@@ -8,6 +8,7 @@
 #include <torch/csrc/jit/api/module.h>
 #include <torch/csrc/jit/ir/ir.h>
 #include <torch/csrc/jit/passes/freeze_module.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/script.h>
 #include <torch/torch.h>
 
@@ -41,10 +42,30 @@ struct NativeNet {
     int pc = 0, vc = 0;
 };
 
+// live timing of the trunk convolution kernel (profile mode): HIP event pairs on the stream the kernel is launched on
+struct ConvProfile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;          // pairs, resolved lazily
+    double ms = 0.0;
+    int64_t launches = 0, boards = 0;
+    void resolve() {
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float t = 0.0f;
+            (void)hipEventSynchronize(ev[i + 1]);
+            (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+            ms += t;
+            (void)hipEventDestroy(ev[i]);
+            (void)hipEventDestroy(ev[i + 1]);
+        }
+        ev.clear();
+    }
+};
+
 struct Model {
     torch::jit::Module module;
     int device = 0;
     NativeNet native;
+    ConvProfile prof;
 };
 
 // scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta  (BatchNorm2d eval, eps = 1e-5)
@@ -141,19 +162,32 @@ bool epilogue(at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, c
 
 // Trunk entirely in hand-written kernels: stem (VALU) -> residual blocks (Winograd on fp32 MFMA, cnn_wino.hip) -> both
 // 1x1 heads, activations in layout W; only the three small fully connected layers go through the BLAS library.
-bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::Tensor& v) {
+bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::Tensor& v, ConvProfile* prof) {
     const int B = (int)in.size(0), P = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3);
     auto opts = in.options();
     at::Tensor x = at::empty({ B, 4096 }, opts), y = at::empty({ B, 4096 }, opts), z = at::empty({ B, 4096 }, opts);
     if (sprl_stem_conv3x3_w(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
                             n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, nullptr) != 0)
         return false;
+    auto conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
+                    at::Tensor& dst) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        if (timed) (void)hipEventRecord(e0, nullptr);
+        const int rc = sprl_wino_conv64(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res,
+                                        dst.data_ptr<float>(), B, H, W, 1, nullptr);
+        if (timed) {
+            (void)hipEventRecord(e1, nullptr);
+            prof->ev.push_back(e0);
+            prof->ev.push_back(e1);
+            prof->launches++;
+            prof->boards += B;
+            if (prof->ev.size() >= 8192) prof->resolve();
+        }
+        return rc == 0;
+    };
     for (const auto& b : n.blocks) {
-        if (sprl_wino_conv64(x.data_ptr<float>(), b.u1.data_ptr<float>(), b.s1.data_ptr<float>(), b.t1.data_ptr<float>(), nullptr,
-                             y.data_ptr<float>(), B, H, W, 1, nullptr) != 0 ||
-            sprl_wino_conv64(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(), b.t2.data_ptr<float>(),
-                             x.data_ptr<float>(), z.data_ptr<float>(), B, H, W, 1, nullptr) != 0)
-            return false;
+        if (!conv(x, b.u1, b.s1, b.t1, nullptr, y) || !conv(y, b.u2, b.s2, b.t2, x.data_ptr<float>(), z)) return false;
         std::swap(x, z);
     }
     const int HW = H * W;
@@ -163,12 +197,12 @@ bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::T
                                    p.data_ptr<float>(), v.data_ptr<float>(), B, 64, HW, n.pc, n.vc, W, nullptr) == 0;
 }
 
-bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value) {
+bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof) {
     at::Tensor p, v;
     const int H0 = (int)in.size(2), W0 = (int)in.size(3), P0 = (int)in.size(1);
     const bool wino = n.wino && (P0 == 3 || P0 == 17) && ((H0 == 8 && W0 == 8) || (H0 == 6 && W0 == 7) || (H0 == 7 && W0 == 7));
     if (wino) {
-        if (!forward_wino(n, in, p, v)) return false;
+        if (!forward_wino(n, in, p, v, prof)) return false;
     } else {
         at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
         if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
@@ -278,7 +312,7 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
                         : torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCPU);
         auto in = torch::from_blob(const_cast<float*>(planes), { batch, nplanes, rows, cols }, opts);
         at::Tensor lo, va;
-        if (!(m->native.ok && forward_native(m->native, in, lo, va))) {
+        if (!(m->native.ok && forward_native(m->native, in, lo, va, &m->prof))) {
             auto out = m->module.forward({ in }).toTuple();         // GridNetwork.hpp:99-102 (generic TorchScript path)
             lo = out->elements()[0].toTensor();
             va = out->elements()[1].toTensor();
@@ -298,6 +332,16 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
 
 // host -> host: conv weight [64][64][3][3] to the Winograd-domain layout sprl_wino_conv64 takes (36*64*64 floats)
 void sprl_wino_transform_weights(const float* w, float* u) { wino_transform(w, u); }
+
+// profile mode: time every trunk-convolution launch with HIP events; totals since load (ms, launches, boards)
+void sprl_torch_profile_enable(void* handle, int on) { static_cast<Model*>(handle)->prof.on = on != 0; }
+void sprl_torch_profile_read(void* handle, double* conv_ms, int64_t* launches, int64_t* boards) {
+    ConvProfile& p = static_cast<Model*>(handle)->prof;
+    p.resolve();
+    if (conv_ms) *conv_ms = p.ms;
+    if (launches) *launches = p.launches;
+    if (boards) *boards = p.boards;
+}
 
 void sprl_torch_free(void* handle) { delete static_cast<Model*>(handle); }
 

@@ -53,7 +53,8 @@ class Stats(C.Structure):
         "nn_batches", "nn_rows")] + [("seconds_total", C.c_double), ("kernel_ms", C.c_double), ("nn_ms", C.c_double),
                           ("hbm_bytes", C.c_int64)] + [(n, C.c_int64) for n in (
         "cyc_total", "cyc_finish", "cyc_move", "cyc_select", "cyc_create", "cyc_backup", "cyc_leafio", "cyc_noise",
-        "cyc_max_slot_launch", "cyc_lvl_wait", "cyc_lvl_pick", "cyc_lvl_desc")]
+        "cyc_max_slot_launch", "cyc_lvl_wait", "cyc_lvl_pick", "cyc_lvl_desc")] + [
+        ("conv_ms", C.c_double), ("conv_launches", C.c_int64), ("conv_boards", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
