@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
     const f4* ua = (const f4*)u + kb * 64 + lane;
     f4 a[9];
     auto aload = [&](int s, int k) {
-        a[k] = (ABL & 4) ? (f4){ (float)s, 1.0f, 2.0f, (float)k } : ua[(size_t)k * (16 * 4 * 64) + s * 256];
+        a[k] = (ABL & 4) ? (f4){ (float)s, 1.0f, 2.0f, (float)k } : (ABL & 32) ? ua[(k & 1) * 256] : ua[(size_t)k * (16 * 4 * 64) + s * 256];
     };
     auto mma = [&](const float* vg, int k) {
 #pragma unroll

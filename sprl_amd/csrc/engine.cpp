@@ -109,6 +109,7 @@ struct sprl_engine {
     // accounting
     int64_t rounds = 0, launches = 0, nn_batches = 0, nn_rows = 0;
     int nn_bucket = 1024;
+    bool nn_bucket_set = false;
     double seconds = 0.0, kernel_ms = 0.0, nn_ms = 0.0;
     std::vector<void*> marks;  // k0,k1,(n0,n1) per round, resolved lazily
     std::vector<int> mark_kind;
@@ -169,9 +170,16 @@ int load_network(sprl_engine* e, const char* model, void** out) {
     char err[512] = { 0 };
     void* m = e->torch.load(model, e->cfg.device, err, (int)sizeof(err));
     if (!m) return fail(SPRL_E_MODEL, std::string("cannot load TorchScript model '") + model + "': " + err);
+    // The hand-written CNN (plugin kind 2) has no per-shape solver selection, so its batches are padded to 64 rows only;
+    // library convolutions pick a solver per shape, so those batches come in 1024-row buckets, each touched once here.
+    const int kind = e->torch.is_native ? e->torch.is_native(m) : 0;
+    const int bucket = kind == 2 ? 64 : 1024;
+    if (bucket > e->nn_bucket || !e->nn_bucket_set) e->nn_bucket = bucket;
+    e->nn_bucket_set = true;
     const int max_rows = e->P.num_slots * e->P.max_queue;
+    const int step_rows = kind == 2 ? (max_rows > 4096 ? max_rows / 4 : max_rows) : e->nn_bucket;
     int last = 0;
-    for (int rows = e->nn_bucket;; rows += e->nn_bucket) {
+    for (int rows = step_rows;; rows += step_rows) {
         int b = rows < max_rows ? rows : max_rows;
         if (b == last) break;
         last = b;

@@ -51,10 +51,12 @@ int main(int argc, char** argv) {
     hipMemcpy(sc, h.data(), 256, hipMemcpyHostToDevice);
     hipMemcpy(sh, h.data(), 256, hipMemcpyHostToDevice);
     printf("batch %d, us per launch\n", B);
-    for (int sg = 0; sg <= 8; sg += 2) printf("v2 full, stagger %d            %8.1f\n", sg, run2<0>(x, u, sc, sh, r, y, B, 20, sg));
+    for (int sg = 4; sg <= 8; sg += 2) printf("v2 full, stagger %d            %8.1f\n", sg, run2<0>(x, u, sc, sh, r, y, B, 20, sg));
     printf("v2 no output stage           %8.1f\n", run2<1>(x, u, sc, sh, r, y, B, 20, 4));
     printf("v2 no V production           %8.1f\n", run2<2>(x, u, sc, sh, r, y, B, 20, 4));
     printf("v2 no weight loads           %8.1f\n", run2<4>(x, u, sc, sh, r, y, B, 20, 4));
+    printf("v2 weights from 8 KB footprint %8.1f\n", run2<32>(x, u, sc, sh, r, y, B, 20, 6));
+    printf("v2 no output, tiny-footprint wts %6.1f\n", run2<33>(x, u, sc, sh, r, y, B, 20, 6));
     printf("v2 no output, no V, no wts   %8.1f\n", run2<7>(x, u, sc, sh, r, y, B, 20, 4));
     printf("v2 skeleton + MFMA           %8.1f\n", run2<23>(x, u, sc, sh, r, y, B, 20, 4));
     printf("full                         %8.1f\n", run<0>(x, u, sc, sh, r, y, B, 20));
