@@ -114,6 +114,91 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ pla
         }
     }
 }
+// The whole tail of the network in one pass over the trunk output (layout W): both 1x1 head convolutions + bias + ReLU
+// (grid_networks.py:44,49), the policy FC, and the value FC -> ReLU -> FC -> tanh (:45,50-51), written straight into the
+// engine's logits / value buffers.  16 boards per workgroup; the head maps of a board stay in LDS between the two
+// stages, the FC weights (<= 50 KB) sit in LDS.  HBM-bound on the 16 KB per board it reads.
+constexpr int TAIL_NB = 16, TAIL_MAXIN = 128, TAIL_MAXA = 80, TAIL_HID = 64;
+
+template <int PC, int VC>
+__global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, const float* __restrict__ hw,
+                                                   const float* __restrict__ hb, const float* __restrict__ pfc_w,
+                                                   const float* __restrict__ pfc_b, const float* __restrict__ vfc1_w,
+                                                   const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
+                                                   const float* __restrict__ vfc2_b, float* __restrict__ logits,
+                                                   float* __restrict__ value, int batch, int H, int W, int A, int HID) {
+    constexpr int OC = PC + VC;
+    __shared__ float s_hw[OC * 64 + OC];
+    __shared__ float s_maps[TAIL_NB][OC * 64];         // [board][o][cell], cell = row * W + col
+    __shared__ float s_pw[TAIL_MAXIN * TAIL_MAXA];
+    __shared__ float s_vw[64 * TAIL_HID];
+    const int tid = (int)threadIdx.x;
+    const int HW = H * W, PIN = PC * HW, VIN = VC * HW;
+    for (int i = tid; i < OC * 64 + OC; i += 256) s_hw[i] = i < OC * 64 ? hw[i] : hb[i - OC * 64];
+    for (int i = tid; i < PIN * A; i += 256) s_pw[i] = pfc_w[i];
+    for (int i = tid; i < VIN * HID; i += 256) s_vw[i] = vfc1_w[i];
+    __syncthreads();
+
+    // stage 1: thread = (board, row-in-tile i, tile): 4 cells x OC maps, all 64 channels
+    const int b = tid >> 4, i = (tid >> 2) & 3, tile = tid & 3;
+    const int n = (int)blockIdx.x * TAIL_NB + b;
+    float acc[OC][4];
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.0f;
+    if (n < batch) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v* xp = (const f4v*)(x + (size_t)n * 4096 + i * 64 + tile * 4);
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g)
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) {
+                const f4v v = __builtin_nontemporal_load(xp + g * 64 + cs * 4);
+                const int k = 16 * (g >> 2) + 4 * cs + (g & 3);
+#pragma unroll
+                for (int o = 0; o < OC; ++o) {
+                    const float w = s_hw[o * 64 + k];
+                    acc[o][0] += w * v.x;
+                    acc[o][1] += w * v.y;
+                    acc[o][2] += w * v.z;
+                    acc[o][3] += w * v.w;
+                }
+            }
+    }
+    const int row = 4 * (tile >> 1) + i, col0 = 4 * (tile & 1);
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (row < H && col0 + j < W) {
+                const float r = acc[o][j] + s_hw[OC * 64 + o];
+                s_maps[b][o * HW + row * W + col0 + j] = r > 0.0f ? r : 0.0f;
+            }
+    __syncthreads();
+
+    // stage 2: thread = (board, t16): policy outputs a = t16, t16 + 16, ...; hidden units j = t16, t16 + 16, ...
+    const int t16 = tid & 15;
+    if (n < batch) {
+        const float* pm = s_maps[b];                   // policy maps first: [PC * HW], then value maps [VC * HW]
+        for (int a = t16; a < A; a += 16) {
+            float sum = pfc_b[a];
+            for (int q = 0; q < PIN; ++q) sum += pm[q] * s_pw[q * A + a];
+            logits[(size_t)n * A + a] = sum;
+        }
+        const float* vm = pm + PIN;
+        float part = 0.0f;
+        for (int j = t16; j < HID; j += 16) {
+            float h = vfc1_b[j];
+            for (int q = 0; q < VIN; ++q) h += vm[q] * s_vw[q * HID + j];
+            h = h > 0.0f ? h : 0.0f;
+            part += h * vfc2_w[j];
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) part += __shfl_xor(part, m, 16);
+        if (t16 == 0) value[n] = tanhf(part + vfc2_b[0]);
+    }
+}
 }  // namespace
 
 // planes: [batch][P][H][W] (the engine's dense network batch), w: [64][P][3][3], y: layout W.  -1: no kernel for this P.
@@ -160,5 +245,22 @@ extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float
     else
         hipLaunchKernelGGL(bn_relu_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)x,
                            (const float4*)nullptr, scale, shift, n_vec, hw / 4, channels);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// x: trunk output in layout W; hw/hb: [PC + VC][64] / [PC + VC] head convolutions (policy rows first); pfc_w: [PC*H*W][A]
+// (transposed Linear weight), vfc1_w: [VC*H*W][HID], vfc2_w: [HID]; logits: [batch][A], value: [batch].  -1: shape not covered.
+extern "C" int sprl_tail_heads_fc(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
+                                  const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                                  float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                                  void* stream) {
+    if (batch <= 0) return 0;
+    if (H > 8 || W > 8 || PC * H * W > TAIL_MAXIN || A > TAIL_MAXA || HID > TAIL_HID || VC * H * W > 64) return -1;
+    const dim3 grid((unsigned)((batch + TAIL_NB - 1) / TAIL_NB)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (PC == 2 && VC == 1)
+        hipLaunchKernelGGL((tail_kernel<2, 1>), grid, block, 0, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
+                           value, batch, H, W, A, HID);
+    else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -25,6 +25,10 @@ extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* sca
 extern "C" int sprl_wino_weight_layout(void);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, void* stream);
+extern "C" int sprl_tail_heads_fc(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
+                                  const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                                  float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                                  void* stream);
 extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const float* bias, float* out_p, float* out_v,
                                        int64_t batch, int C, int HW, int PC, int VC, int board_w, void* stream);
 
@@ -162,7 +166,8 @@ bool epilogue(at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, c
 
 // Trunk entirely in hand-written kernels: stem (VALU) -> residual blocks (Winograd on fp32 MFMA, cnn_wino.hip) -> both
 // 1x1 heads, activations in layout W; only the three small fully connected layers go through the BLAS library.
-bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::Tensor& v, ConvProfile* prof) {
+bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::Tensor& v, ConvProfile* prof, float* logits_out,
+                  float* value_out, bool* wrote_outputs) {
     const int B = (int)in.size(0), P = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3);
     auto opts = in.options();
     at::Tensor x = at::empty({ B, 4096 }, opts), y = at::empty({ B, 4096 }, opts), z = at::empty({ B, 4096 }, opts);
@@ -191,18 +196,29 @@ bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::T
         std::swap(x, z);
     }
     const int HW = H * W;
+    const int A = (int)n.pfc_w.size(1), HID = (int)n.vfc1_w.size(1);
+    if (logits_out && value_out && n.vfc2_w.numel() == HID &&
+        sprl_tail_heads_fc(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(),
+                           n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
+                           n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A,
+                           HID, nullptr) == 0) {
+        *wrote_outputs = true;                   // heads + FC layers fused, results already in the caller's buffers
+        return true;
+    }
     p = at::empty({ B, (int64_t)n.pc * HW }, opts);
     v = at::empty({ B, (int64_t)n.vc * HW }, opts);
     return sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
                                    p.data_ptr<float>(), v.data_ptr<float>(), B, 64, HW, n.pc, n.vc, W, nullptr) == 0;
 }
 
-bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof) {
+bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
+                    float* logits_out, float* value_out, bool* wrote_outputs) {
     at::Tensor p, v;
     const int H0 = (int)in.size(2), W0 = (int)in.size(3), P0 = (int)in.size(1);
     const bool wino = n.wino && (P0 == 3 || P0 == 17) && ((H0 == 8 && W0 == 8) || (H0 == 6 && W0 == 7) || (H0 == 7 && W0 == 7));
     if (wino) {
-        if (!forward_wino(n, in, p, v, prof)) return false;
+        if (!forward_wino(n, in, p, v, prof, logits_out, value_out, wrote_outputs)) return false;
+        if (*wrote_outputs) return true;
     } else {
         at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
         if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
@@ -312,7 +328,12 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
                         : torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCPU);
         auto in = torch::from_blob(const_cast<float*>(planes), { batch, nplanes, rows, cols }, opts);
         at::Tensor lo, va;
-        if (!(m->native.ok && forward_native(m->native, in, lo, va, &m->prof))) {
+        bool wrote = false;
+        const bool fuse_tail = m->device >= 0 && m->native.ok && m->native.pfc_w.size(1) == actions && !getenv("SPRL_TORCH_NO_FUSED_TAIL");
+        if (m->native.ok && forward_native(m->native, in, lo, va, &m->prof, fuse_tail ? logits : nullptr,
+                                           fuse_tail ? value : nullptr, &wrote) && wrote)
+            return 0;
+        if (!lo.defined()) {
             auto out = m->module.forward({ in }).toTuple();         // GridNetwork.hpp:99-102 (generic TorchScript path)
             lo = out->elements()[0].toTensor();
             va = out->elements()[1].toTensor();
