@@ -63,7 +63,10 @@ __global__ void __launch_bounds__(1024) leaf_scan_kernel(const uint32_t* count, 
         offset[i] = run;
         run += count[i];
     }
-    if (t == 1023) counters->leaf_total = part[1023];
+    if (t == 1023) {
+        counters->leaf_total = part[1023];
+        counters->leaf_rows += part[1023];
+    }
 }
 
 // One wavefront per slot copies its <= max_queue leaves (16 B per lane per step) to their dense rows.

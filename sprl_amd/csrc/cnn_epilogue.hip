@@ -75,7 +75,13 @@ __global__ void __launch_bounds__(256) heads_kernel(const float* __restrict__ x,
 template <int P>
 __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ planes, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   float* __restrict__ y, int batch, int H, int W) {
+                                                   float* __restrict__ y, int batch, int H, int W,
+                                                   const unsigned* __restrict__ batch_dev) {
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+        if ((int)blockIdx.x * 4 >= batch) return;
+    }
     __shared__ float img[4][P][100];                   // zero-bordered 10x10 images
     const int tid = (int)threadIdx.x;
     const int n0 = (int)blockIdx.x * 4;
@@ -126,7 +132,13 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
                                                    const float* __restrict__ pfc_b, const float* __restrict__ vfc1_w,
                                                    const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
                                                    const float* __restrict__ vfc2_b, float* __restrict__ logits,
-                                                   float* __restrict__ value, int batch, int H, int W, int A, int HID) {
+                                                   float* __restrict__ value, int batch, int H, int W, int A, int HID,
+                                                   const unsigned* __restrict__ batch_dev) {
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+        if ((int)blockIdx.x * TAIL_NB >= batch) return;
+    }
     constexpr int OC = PC + VC;
     __shared__ float s_hw[OC * 64 + OC];
     __shared__ float s_maps[TAIL_NB][OC * 64];         // [board][o][cell], cell = row * W + col
@@ -203,12 +215,12 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
 
 // planes: [batch][P][H][W] (the engine's dense network batch), w: [64][P][3][3], y: layout W.  -1: no kernel for this P.
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
-                                   int batch, int P, int H, int W, void* stream) {
+                                   int batch, int P, int H, int W, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     if (H > 8 || W > 8) return -1;
     const dim3 grid((unsigned)((batch + 3) / 4)), block(256);
-    if (P == 3) hipLaunchKernelGGL(stem_kernel<3>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W);
-    else if (P == 17) hipLaunchKernelGGL(stem_kernel<17>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W);
+    if (P == 3) hipLaunchKernelGGL(stem_kernel<3>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W, batch_dev);
+    else if (P == 17) hipLaunchKernelGGL(stem_kernel<17>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W, batch_dev);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -253,14 +265,14 @@ extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float
 extern "C" int sprl_tail_heads_fc(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
                                   const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
                                   float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
-                                  void* stream) {
+                                  const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     if (H > 8 || W > 8 || PC * H * W > TAIL_MAXIN || A > TAIL_MAXA || HID > TAIL_HID || VC * H * W > 64) return -1;
     const dim3 grid((unsigned)((batch + TAIL_NB - 1) / TAIL_NB)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (PC == 2 && VC == 1)
         hipLaunchKernelGGL((tail_kernel<2, 1>), grid, block, 0, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
-                           value, batch, H, W, A, HID);
+                           value, batch, H, W, A, HID, batch_dev);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -319,7 +319,14 @@ template <int H, int W, int ABL = 0>
 __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                                   const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                                  int relu, int stagger) {
+                                                                  int relu, int stagger, const unsigned* __restrict__ batch_dev) {
+    // batch_dev != null: the number of boards is on the device (the engine's leaf count of this round), `batch` is the
+    // capacity the grid was sized for; workgroups past the real count leave at once
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+        if ((int)blockIdx.x * NIMG2 >= batch) return;
+    }
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS2];
     float* const in_buf = lds;                        // [2][IN_BUF2]
     float* const v_buf = lds + 2 * IN_BUF2;           // [2 phases][2 groups][V_G2]
@@ -508,20 +515,29 @@ extern "C" int sprl_wino_weight_layout(void) { return getenv("SPRL_WINO_V1") ? 1
 // x, y, res: activations in layout W (4096 floats per board; res may be null; y must not alias x); u: 36*64*64 pre-transformed
 // weights in A-operand order (torch_eval.cpp: wino_transform); scale/shift: [64].  Returns 0, or -1 when the board shape has
 // no kernel here.
+extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                    float* y, int batch, int H, int W, int relu, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                 float* y, int batch, int H, int W, int relu, void* stream) {
+    return sprl_wino_conv64_dev(x, u, scale, shift, res, y, batch, H, W, relu, nullptr, stream);
+}
+
+// batch_dev: optional device pointer to the real board count (<= batch, the capacity); version 2 kernel only
+extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                    float* y, int batch, int H, int W, int relu, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     static const int version = getenv("SPRL_WINO_V1") ? 1 : 2;
     static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
     if (version == 2) {
         const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
-        if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger);
-        else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger);
-        else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger);
+        if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev);
+        else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev);
+        else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev);
         else return -1;
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
+    if (batch_dev) return -1;
     const dim3 grid((unsigned)((batch + NIMG - 1) / NIMG)), block(NTHR);
     if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
     else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);

@@ -79,6 +79,7 @@ struct TorchPlugin {
     int (*forward)(void*, const float*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
     void (*release)(void*) = nullptr;
     int (*is_native)(void*) = nullptr;
+    int (*forward_dev)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
     void (*profile_enable)(void*, int) = nullptr;
     void (*profile_read)(void*, double*, int64_t*, int64_t*) = nullptr;
 };
@@ -110,6 +111,8 @@ struct sprl_engine {
     int64_t rounds = 0, launches = 0, nn_batches = 0, nn_rows = 0;
     int nn_bucket = 1024;
     bool nn_bucket_set = false;
+    bool dev_batch = false;     // the evaluator takes the batch size from device memory: rounds are enqueued without a host sync
+    unsigned long long last_leaf_rows = 0;
     double seconds = 0.0, kernel_ms = 0.0, nn_ms = 0.0;
     std::vector<void*> marks;  // k0,k1,(n0,n1) per round, resolved lazily
     std::vector<int> mark_kind;
@@ -155,6 +158,8 @@ int load_torch_plugin(sprl_engine* e) {
     e->torch.forward = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, char*, int))dlsym(lib, "sprl_torch_forward");
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
     e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
+    e->torch.forward_dev = (int (*)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, char*, int))dlsym(
+        lib, "sprl_torch_forward_dev");
     e->torch.profile_enable = (void (*)(void*, int))dlsym(lib, "sprl_torch_profile_enable");
     e->torch.profile_read = (void (*)(void*, double*, int64_t*, int64_t*))dlsym(lib, "sprl_torch_profile_read");
     if (!e->torch.load || !e->torch.forward || !e->torch.release)
@@ -334,6 +339,7 @@ void sprl_engine_destroy(sprl_engine* e) {
 int sprl_engine_set_model(sprl_engine* e, const char* model) {
     if (!e || !model) return fail(SPRL_E_CONFIG, "null argument");
     if (e->running) return fail(SPRL_E_STATE, "cannot change the evaluator while a run is in progress");
+    e->dev_batch = false;
     if (strcmp(model, "random") == 0) {          // GridWorker.hpp:36-38,125-127
         e->eval_kind = SPRL_EVAL_RANDOM;
         return 0;
@@ -348,6 +354,13 @@ int sprl_engine_set_model(sprl_engine* e, const char* model) {
     if (rc) return rc;
     if (e->torch_model) e->torch.release(e->torch_model);
     e->torch_model = m;
+    {   // can this model run with the leaf count left on the device?  (probe with the current count, normally 0)
+        char perr[256] = { 0 };
+        e->dev_batch = e->torch.forward_dev && !getenv("SPRL_SYNC_ROUNDS") &&
+                       e->torch.forward_dev(m, e->P.nn_dense, &e->P.counters->leaf_total, e->P.num_slots * e->P.max_queue, e->g.planes,
+                                            e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, perr, (int)sizeof(perr)) == 0;
+        be::sync();
+    }
     if (e->cfg.profile && e->torch.profile_enable) e->torch.profile_enable(m, 1);
     e->forward_cb = nullptr;
     e->eval_kind = SPRL_EVAL_NETWORK;
@@ -394,6 +407,7 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
         if (!ok) return fail(SPRL_E_DEVICE, std::string("record allocation failed (") + be::last_error() + ")");
     }
     e->num_games = num_games;
+    e->last_leaf_rows = 0;
     P.num_games = num_games;
     P.eval_kind = e->eval_kind;
     std::vector<GameCtl> ctl((size_t)P.num_slots);
@@ -447,6 +461,32 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
             // dense batch: only the leaves that were really queued, slot-major (deterministic), in buckets of
             // `bucket` rows so the convolution library sees a handful of shapes
             if (be::launch_compact(P, floats_per_leaf) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+            if (e->dev_batch && !e->forward_cb) {
+                // the evaluator reads the leaf count from the device: no host round trip between rounds; completion and
+                // errors are looked at every 8 rounds (rounds after the last game ended find nothing to do)
+                void* n0 = e->cfg.profile ? be::mark() : nullptr;
+                char err[512] = { 0 };
+                if (e->torch.forward_dev(e->torch_model, P.nn_dense, &P.counters->leaf_total, max_batch_rows, e->g.planes, e->g.rows,
+                                         e->g.cols, e->nn_logits, e->g.A, e->nn_value, err, (int)sizeof(err)) != 0) {
+                    e->running = false;
+                    return fail(SPRL_E_MODEL, std::string("network forward failed: ") + err);
+                }
+                if (e->cfg.profile) {
+                    e->marks.push_back(n0);
+                    e->marks.push_back(be::mark());
+                    e->mark_kind.push_back(1);
+                }
+                e->nn_batches++;
+                if ((r & 7) == 7 || r == launches - 1) {
+                    if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+                    e->nn_rows += (int64_t)(c.leaf_rows - e->last_leaf_rows);
+                    e->last_leaf_rows = c.leaf_rows;
+                    if (c.error != ERR_NONE) break;
+                    if (c.games_done >= (uint32_t)e->num_games && c.active_slots == 0 && c.leaf_total == 0) break;
+                }
+                if (e->marks.size() >= 4096) resolve_marks(e);
+                continue;
+            }
             if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
             if (c.error != ERR_NONE) break;
             const int bucket = e->nn_bucket;
@@ -744,7 +784,12 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
     out->nn_ms = e->nn_ms;
     out->hbm_bytes = (int64_t)e->hbm_bytes;
     if (e->torch_model && e->torch.profile_read && e->cfg.profile)
+    {
         e->torch.profile_read(e->torch_model, &out->conv_ms, &out->conv_launches, &out->conv_boards);
+        // with the batch size left on the device the plugin only knows the capacity: the real rows are the engine's count
+        if (e->dev_batch && e->nn_batches > 0)
+            out->conv_boards = (int64_t)((double)e->nn_rows * (double)out->conv_launches / (double)e->nn_batches);
+    }
     return 0;
 }
 

@@ -86,7 +86,7 @@ struct Counters {
     uint32_t error_game;
     uint32_t active_slots;  // slots still holding an unfinished game after the last step
     uint32_t leaf_total;    // leaves queued for the network by the last step (dense batch size)
-    uint32_t pad[2];
+    unsigned long long leaf_rows;   // running sum of leaf_total over the launches of a run (rows evaluated by the network)
 };
 
 struct alignas(32) Mailbox {   // match play: the move a side has just made, handed to the partner tree of the same game

@@ -20,15 +20,15 @@
 
 extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float* scale, const float* shift,
                                     int64_t numel, int channels, int hw, void* stream);
-extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res,
-                                float* y, int batch, int H, int W, int relu, void* stream);
+extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                    float* y, int batch, int H, int W, int relu, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_wino_weight_layout(void);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
-                                   int batch, int P, int H, int W, void* stream);
+                                   int batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_tail_heads_fc(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
                                   const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
                                   float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
-                                  void* stream);
+                                  const unsigned* batch_dev, void* stream);
 extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const float* bias, float* out_p, float* out_v,
                                        int64_t batch, int C, int HW, int PC, int VC, int board_w, void* stream);
 
@@ -167,20 +167,20 @@ bool epilogue(at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, c
 // Trunk entirely in hand-written kernels: stem (VALU) -> residual blocks (Winograd on fp32 MFMA, cnn_wino.hip) -> both
 // 1x1 heads, activations in layout W; only the three small fully connected layers go through the BLAS library.
 bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::Tensor& v, ConvProfile* prof, float* logits_out,
-                  float* value_out, bool* wrote_outputs) {
+                  float* value_out, bool* wrote_outputs, const unsigned* batch_dev = nullptr) {
     const int B = (int)in.size(0), P = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3);
     auto opts = in.options();
     at::Tensor x = at::empty({ B, 4096 }, opts), y = at::empty({ B, 4096 }, opts), z = at::empty({ B, 4096 }, opts);
     if (sprl_stem_conv3x3_w(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
-                            n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, nullptr) != 0)
+                            n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, batch_dev, nullptr) != 0)
         return false;
     auto conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
                     at::Tensor& dst) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
         if (timed) (void)hipEventRecord(e0, nullptr);
-        const int rc = sprl_wino_conv64(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res,
-                                        dst.data_ptr<float>(), B, H, W, 1, nullptr);
+        const int rc = sprl_wino_conv64_dev(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(),
+                                            res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, nullptr);
         if (timed) {
             (void)hipEventRecord(e1, nullptr);
             prof->ev.push_back(e0);
@@ -201,10 +201,11 @@ bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::T
         sprl_tail_heads_fc(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(),
                            n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
                            n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A,
-                           HID, nullptr) == 0) {
+                           HID, batch_dev, nullptr) == 0) {
         *wrote_outputs = true;                   // heads + FC layers fused, results already in the caller's buffers
         return true;
     }
+    if (batch_dev) return false;                 // the device-side count needs the fused tail
     p = at::empty({ B, (int64_t)n.pc * HW }, opts);
     v = at::empty({ B, (int64_t)n.vc * HW }, opts);
     return sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
@@ -362,6 +363,30 @@ void sprl_torch_profile_read(void* handle, double* conv_ms, int64_t* launches, i
     if (conv_ms) *conv_ms = p.ms;
     if (launches) *launches = p.launches;
     if (boards) *boards = p.boards;
+}
+
+// The whole forward with the batch size read ON THE DEVICE (`batch_dev`, <= max_batch): nothing here depends on the host
+// knowing how many leaves the round queued, so the engine can enqueue rounds without a synchronisation in between.
+// Only the hand-written path (kind 2 with the fused tail) can do this; returns -2 when it cannot.
+int sprl_torch_forward_dev(void* handle, const float* planes, const unsigned* batch_dev, int max_batch, int nplanes, int rows,
+                           int cols, float* logits, int actions, float* value, char* err, int errlen) {
+    try {
+        auto* m = static_cast<Model*>(handle);
+        const NativeNet& n = m->native;
+        if (!(n.ok && n.wino) || m->device < 0 || n.pfc_w.size(1) != actions || getenv("SPRL_TORCH_NO_FUSED_TAIL")) return -2;
+        if (!((nplanes == 3 || nplanes == 17) && ((rows == 8 && cols == 8) || (rows == 6 && cols == 7) || (rows == 7 && cols == 7))))
+            return -2;
+        c10::InferenceMode guard;
+        auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, (c10::DeviceIndex)m->device);
+        auto in = torch::from_blob(const_cast<float*>(planes), { max_batch, nplanes, rows, cols }, opts);
+        at::Tensor p, v;
+        bool wrote = false;
+        if (!forward_wino(n, in, p, v, &m->prof, logits, value, &wrote, batch_dev) || !wrote) return -2;
+        return 0;
+    } catch (const std::exception& e) {
+        put_err(err, errlen, e.what());
+        return -1;
+    }
 }
 
 void sprl_torch_free(void* handle) { delete static_cast<Model*>(handle); }

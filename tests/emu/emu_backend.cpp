@@ -78,6 +78,7 @@ int launch_compact(const EngineParams& P, int floats_per_leaf) {
         run += P.leaf_count[s];
     }
     P.counters->leaf_total = run;
+    P.counters->leaf_rows += run;
     return 0;
 }
 void* mark() {
