@@ -8,6 +8,7 @@
 // float4 never straddles channels).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 template <bool RESIDUAL>
@@ -120,6 +121,83 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ pla
         }
     }
 }
+// Stem for 3 input planes on the fp32 matrix core: per board out[64 ch][64 cells] = W[64][27] x patches[27][64] as
+// v_mfma_f32_16x16x4_f32 (K padded to 28 = 7 steps; exact fp32 multiply-adds like the VALU form).  One wave per board:
+// the weight fragments (4 channel blocks x 7 steps) stay in 28 registers for the whole kernel, the patch fragments are
+// single LDS reads from the zero-bordered planes, and with the cell order (row-in-tile, tile, column) a store
+// instruction writes one full 256-byte row of layout W.
+typedef float stem_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict__ planes, const float* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        float* __restrict__ y, int batch, int H, int W,
+                                                        const unsigned* __restrict__ batch_dev) {
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+    }
+    __shared__ float img[4][3][100];                   // per wave: zero-bordered 10x10 planes of its board
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qs = lane >> 4, l16 = lane & 15;         // K slot of this lane inside a step, column of the 16x16 tile
+    const int tile = l16 >> 2, j = l16 & 3;
+    // A fragments: lane -> (channel 16 kb + l16, K index 4 s + qs)
+    float a[4][7];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7) {
+            const int q = 4 * s7 + qs;
+            a[kb][s7] = q < 27 ? w[(16 * kb + l16) * 27 + q] : 0.0f;
+        }
+    // B fragments: lane -> (K index 4 s + qs, cell (i = cb, tile, j)); offset of tap q = plane * 100 + dy * 10 + dx
+    int qoff[7];
+#pragma unroll
+    for (int s7 = 0; s7 < 7; ++s7) {
+        const int q = 4 * s7 + qs;
+        qoff[s7] = q < 27 ? (q / 9) * 100 + ((q % 9) / 3) * 10 + (q % 3) : -1;
+    }
+    const int cell0 = (4 * (tile >> 1)) * 10 + 4 * (tile & 1) + j;     // + cb * 10 for row-in-tile cb
+    const int col = 4 * (tile & 1) + j;
+    float sc[4][4], sh[4][4];                          // channel 16 kb + 4 qs + r  (row of the accumulator tile)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[kb][r] = scale[16 * kb + 4 * qs + r];
+            sh[kb][r] = shift[16 * kb + 4 * qs + r];
+        }
+    const int HW = H * W;
+    float* im = &img[wave][0][0];
+    for (int i = lane; i < 300; i += 64) im[i] = 0.0f;
+    const int nwaves = (int)gridDim.x * 4;
+    for (int n = (int)blockIdx.x * 4 + wave; n < batch; n += nwaves) {
+        for (int e = lane; e < 3 * HW; e += 64) {
+            const int p = e / HW, cell = e % HW;
+            im[p * 100 + (cell / W + 1) * 10 + cell % W + 1] = planes[(size_t)n * 3 * HW + e];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            stem_f4 acc[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb] = (stem_f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int s7 = 0; s7 < 7; ++s7) {
+                const float b = qoff[s7] >= 0 ? im[qoff[s7] + cell0 + cb * 10] : 0.0f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb][s7], b, acc[kb], 0, 0, 0);
+            }
+            const bool on_board = 4 * (tile >> 1) + cb < H && col < W;
+            float* yo = y + (size_t)n * 4096 + cb * 64 + qs * 16 + l16;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[kb][r] * sc[kb][r] + sh[kb][r];
+                    yo[(4 * kb + r) * 256] = on_board ? (v > 0.0f ? v : 0.0f) : 0.0f;
+                }
+        }
+    }
+}
+
 // The whole tail of the network in one pass over the trunk output (layout W): both 1x1 head convolutions + bias + ReLU
 // (grid_networks.py:44,49), the policy FC, and the value FC -> ReLU -> FC -> tanh (:45,50-51), written straight into the
 // engine's logits / value buffers.  16 boards per workgroup; the head maps of a board stay in LDS between the two
@@ -219,7 +297,12 @@ extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const fl
     if (batch <= 0) return 0;
     if (H > 8 || W > 8) return -1;
     const dim3 grid((unsigned)((batch + 3) / 4)), block(256);
-    if (P == 3) hipLaunchKernelGGL(stem_kernel<3>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W, batch_dev);
+    if (P == 3 && !getenv("SPRL_STEM_VALU")) {
+        int blocks = (batch + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;        // grid-stride over boards: the weight fragments are loaded once per wave
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)blocks), block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W,
+                           batch_dev);
+    } else if (P == 3) hipLaunchKernelGGL(stem_kernel<3>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W, batch_dev);
     else if (P == 17) hipLaunchKernelGGL(stem_kernel<17>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W, batch_dev);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;

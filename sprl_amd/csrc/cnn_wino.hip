@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
                     if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                     if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;       // cells off the board stay zero
                 }
-                __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
+                if (!(ABL & 64) || v[0] == 123.456f) __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
             }
         }
         if (r + 2 < 4) rload(r + 2);

@@ -51,7 +51,10 @@ int main(int argc, char** argv) {
     hipMemcpy(sc, h.data(), 256, hipMemcpyHostToDevice);
     hipMemcpy(sh, h.data(), 256, hipMemcpyHostToDevice);
     printf("batch %d, us per launch\n", B);
-    for (int sg = 4; sg <= 8; sg += 2) printf("v2 full, stagger %d            %8.1f\n", sg, run2<0>(x, u, sc, sh, r, y, B, 20, sg));
+    for (int sg = 6; sg <= 6; sg += 2) printf("v2 full, stagger %d            %8.1f\n", sg, run2<0>(x, u, sc, sh, r, y, B, 20, sg));
+    printf("v2 no residual               %8.1f\n", run2<0>(x, u, sc, sh, nullptr, y, B, 20, 6));
+    printf("v2 no stores                 %8.1f\n", run2<64>(x, u, sc, sh, r, y, B, 20, 6));
+    printf("v2 no stores, no residual    %8.1f\n", run2<64>(x, u, sc, sh, nullptr, y, B, 20, 6));
     printf("v2 no output stage           %8.1f\n", run2<1>(x, u, sc, sh, r, y, B, 20, 4));
     printf("v2 no V production           %8.1f\n", run2<2>(x, u, sc, sh, r, y, B, 20, 4));
     printf("v2 no weight loads           %8.1f\n", run2<4>(x, u, sc, sh, r, y, B, 20, 4));
