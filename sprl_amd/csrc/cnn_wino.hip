@@ -70,12 +70,23 @@ __device__ __forceinline__ void inverse_transform(const float (&m)[6][6], float 
 }
 
 // ABL: ablation switches for tools/wino_ablate.hip only (0 in the product): 1 no output stage, 2 no V production,
-// 4 no weight loads, 8 no MFMAs, 16 no activation loads
+// 4 no weight loads, 8 no MFMAs, 16 no activation loads, 32 weights from an 8 KB footprint, 64 no stores
+//
+// Version 3 (8 waves = 8 boards = 32 tiles, one workgroup per CU): wave (kb, tb) owns output channels 16kb..16kb+15 for
+// all 36 transform positions of tile block tb.  The two waves of a kb request the same weight fragments within a few
+// hundred cycles of each other, so the second request is served by the CU's vector cache and the L2 -> CU weight traffic
+// is half of version 2's (590 KB per 8 boards instead of per 4) - the quantity that bounds version 2 (about 70 GB/s per
+// CU from L2).  In-register inverse transform as in version 2; no second resident workgroup to overlap with.
 template <int H, int W, int ABL = 0>
 __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                           int relu) {
+                                                           int relu, const unsigned* __restrict__ batch_dev) {
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+        if ((int)blockIdx.x * NIMG >= batch) return;
+    }
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* const in_buf = lds;                        // [2][IN_BUF]
     float* const v_buf = lds + 2 * IN_BUF;            // [2 phases][2 groups][V_BUF]
@@ -85,27 +96,23 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
     const int n0 = (int)blockIdx.x * NIMG;
     // producer role: group gl of the chunk, tile block tbp, transform rows xi in 3wa..3wa+2 (all six nu)
     const int gl = wave & 1, tbp = (wave >> 1) & 1, wa = wave >> 2;
-    // consumer role: output channels 16kb.., positions 18half..
-    const int kb = wave & 3, half = wave >> 2;
+    // consumer role: output channels 16kb.., tile block tb (waves kb and kb + 4 share a SIMD and the weight fragments)
+    const int kb = wave & 3, tb = wave >> 2;
 
     for (int i = tid; i < 2 * IN_BUF; i += NTHR) lds[i] = 0.0f;   // borders stay zero for the whole kernel
 
-    f4 acc[18][2];
+    f4 acc[36];
 #pragma unroll
-    for (int q = 0; q < 18; ++q)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[q][tb] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int q = 0; q < 36; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
 
-    // chunk = groups 2c, 2c+1 of 8 boards: 1024 float4, two per thread.  float4 f of a board's chunk:
-    // f = ((gl * 4 + i) * 4 + cs) * 4 + tile  ->  channel slot gl * 4 + cs, row 4 ty + i, columns 4 tx .. 4 tx + 3
     f4 pre[2];                                        // one chunk in flight from HBM (a full phase to land)
     int ldst[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int f = tid + NTHR * it;
         const int b = f >> 7, rem = f & 127;
-        const int gl = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
-        ldst[it] = (gl * 4 + cs) * CS + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
+        const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
+        ldst[it] = (g2 * 4 + cs) * CS + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
     }
     auto gload = [&](int chunk) {
 #pragma unroll
@@ -123,9 +130,6 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = pre[it][j];
     };
-    // V of chunk c (groups 2c, 2c+1): this thread's channel slot gl * 4 + c_sub, tile 16 tbp + tl, rows 3wa..3wa+2 of
-    // V = B^T d B.  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]: rows 0-2
-    // need patch rows 0-4, rows 3-5 need patch rows 1-5, and rows 5 and 0 are the same stencil one step apart.
     const int patch0 = (gl * 4 + c_sub) * CS + board_off(tbp * 4 + (tl >> 2)) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
     const int vdst0 = gl * V_BUF + (3 * wa) * 6 * 128 + tbp * 64 + lane;
     auto produce = [&](int c) {
@@ -160,50 +164,37 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
             vd[(r * 6 + 5) * 128] = 4.0f * w1 - 5.0f * w3 + w5;
         }
     };
-    // A operand: U2[p][s][kb][lane], p = xi * 6 + nu, lane -> (k = 16kb + lane%16, input channel = slot lane/16 of group s)
-    const float* ua = u + (size_t)(18 * half) * (16 * 4 * 64) + kb * 64 + lane;
-    const float* vsrc = v_buf + (18 * half) * 128 + lane;
-
-    // weights and MFMAs of one chunk (two groups) for this wave, in six slices of six transform positions.  The weights
-    // live in a 36-register ring that runs one whole chunk ahead: as soon as a slice's MFMAs are issued its registers are
-    // reloaded with the same slice of the next chunk (~1 us of MFMA work covers an L2 miss).
-    float a[6][6];
-    auto aload = [&](int c, int k) {
-        const int s = 2 * c + k / 3, q0 = (k % 3) * 6;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) a[k][q] = (ABL & 4) ? (float)(q + s) : ua[(size_t)(q0 + q) * (16 * 4 * 64) + s * 256];
+    // A operand: U4[p / 4][s][kb][lane][p % 4]; a 36-register ring one group ahead
+    const f4* ua = (const f4*)u + kb * 64 + lane;
+    f4 a[9];
+    auto aload = [&](int s, int k) {
+        a[k] = (ABL & 4) ? (f4){ (float)s, 1.0f, 2.0f, (float)k } : (ABL & 32) ? ua[(k & 1) * 256] : ua[(size_t)k * (16 * 4 * 64) + s * 256];
     };
-    auto mma = [&](const float* vs, int k) {
-        const float* vk = vs + (k / 3) * V_BUF + (k % 3) * 6 * 128;
+    const float* vsrc = v_buf + tb * 64 + lane;
+    auto mma = [&](const float* vg, int k) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const float b0 = vk[q * 128], b1 = vk[q * 128 + 64];
-            const int qq = (k % 3) * 6 + q;
-            if (ABL & 8) {
-                acc[qq][0][0] += a[k][q] * b0;
-                acc[qq][1][0] += a[k][q] * b1;
-            } else {
-                acc[qq][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b0, acc[qq][0], 0, 0, 0);
-                acc[qq][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b1, acc[qq][1], 0, 0, 0);
-            }
+        for (int q = 0; q < 4; ++q) {
+            const float b = vg[(k * 4 + q) * 128];
+            if (ABL & 8) acc[k * 4 + q][0] += a[k][q] * b;
+            else acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
         }
     };
-    // phase c: MFMAs on V(c) while V(c+1) is built; at its end chunk c+2 goes to LDS and chunk c+3 is requested from HBM.
-    // Memory-counter order matters (vmcnt retires in order): every weight load is consumed a whole phase after it was
-    // issued and the HBM request a whole phase after it was issued, so no wait ever lands on a young HBM request.
-    // The two waves of a SIMD (half 0 / half 1) run produce and MFMA in opposite order, so one does VALU/LDS work while
-    // the other feeds the matrix core.
+    // the two waves of a SIMD (tb 0 / tb 1) run produce and MFMA in opposite order
     auto phase = [&](int c) {
         const float* vs = vsrc + (c & 1) * 2 * V_BUF;
-        if (half == 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
+        if (tb == 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            mma(vs, k);
-            if (c + 1 < 8) aload(c + 1, k);
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int s = 2 * c + g2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                mma(vs + g2 * V_BUF, k);
+                if (s + 1 < 16) aload(s + 1, k);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (half != 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
+        if (tb != 0 && c + 1 < 8 && !(ABL & 2)) produce(c + 1);
         if (c + 2 < 8) {
             lstore(in_buf + (c & 1) * IN_BUF);         // in_buf[c & 1]: V(c) was built in phase c - 1
             if (c + 3 < 8) gload(c + 3);
@@ -211,9 +202,7 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
         __syncthreads();
     };
 
-    // residual rows of output component r (channel 16 kb + 4 c_sub + r) of this lane's tile: requested two components ahead of
-    // their use (the first two before the LDS exchange), so that HBM latency hides behind LDS traffic and arithmetic
-    const int t_out = 16 * half + tl;                 // tile this lane finishes
+    const int t_out = 16 * tb + tl;                   // this lane's tile
     const int n = n0 + (t_out >> 2), tile = t_out & 3;
     const size_t plane0 = (size_t)n * 4096 + (size_t)(4 * kb) * 256 + (size_t)(c_sub * 16 + tile * 4);
     f4 rres[4][4];
@@ -229,7 +218,7 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
     lstore(in_buf);
     gload(1);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) aload(0, k);
+    for (int k = 0; k < 9; ++k) aload(0, k);
     lstore(in_buf + IN_BUF);
     gload(2);
     __syncthreads();
@@ -240,65 +229,41 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
     if (ABL & 1) {
         float sum = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 18; ++q) sum += acc[q][0][0] + acc[q][1][1] + acc[q][0][2] + acc[q][1][3];
+        for (int q = 0; q < 36; ++q) sum += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
         if (sum == 123.456f) y[tid] = sum;
         return;
     }
 
-    // ---- the two waves of a kb swap halves: wave (kb, half) ends up with all 36 positions of tile block `half` ----
-    // (written twice, once per value of the wave-uniform `half`, so that every register index is static).  Two rounds of
-    // two accumulator components each keep the live registers under the 256 budget with the residual rows in flight.
-    f2* const xch = (f2*)lds;                          // [8 waves][18][64 lanes] float2 = 72 KB
-    const int partner = wave ^ 4;
-    auto finish = [&](auto half_c) {
-        constexpr int HALF = decltype(half_c)::value;
-        const int ty = tile >> 1, tx = tile & 1;
-        rload(0);
-        rload(1);
+    // ---- inverse transform in registers + epilogue ----
+    const int ty = tile >> 1, tx = tile & 1;
+    rload(0);
+    rload(1);
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            f2 other[18];                              // the partner's positions of MY tile block, components 2 round, 2 round + 1
+    for (int r = 0; r < 4; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        float m[6][6];
 #pragma unroll
-            for (int q = 0; q < 18; ++q)
-                xch[(wave * 18 + q) * 64 + lane] = (f2){ acc[q][1 - HALF][2 * round], acc[q][1 - HALF][2 * round + 1] };
-            __syncthreads();
+        for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = acc[p][r];
+        float o[4][4];
+        inverse_transform(m, o);
+        const int k = 16 * kb + 4 * c_sub + r;
+        const float sc = scale[k], sh = shift[k];
+        if (n < batch) {
 #pragma unroll
-            for (int q = 0; q < 18; ++q) other[q] = xch[(partner * 18 + q) * 64 + lane];
-            __syncthreads();
+            for (int i = 0; i < 4; ++i) {
+                f4 v;
+                const f4 rv = rres[r][i];
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r = 2 * round + rr;
-                __builtin_amdgcn_sched_barrier(0);     // keep one component's loads/stores from piling onto the next
-                float m[6][6];
-#pragma unroll
-                for (int p = 0; p < 18; ++p) {
-                    m[p / 6][p % 6] = HALF ? other[p][rr] : acc[p][0][r];
-                    m[(p + 18) / 6][(p + 18) % 6] = HALF ? acc[p][1][r] : other[p][rr];
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = o[i][j] * sc + sh + rv[j];
+                    if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                    if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;       // cells off the board stay zero
                 }
-                float o[4][4];
-                inverse_transform(m, o);
-                const int k = 16 * kb + 4 * c_sub + r;
-                const float sc = scale[k], sh = shift[k];
-                if (n < batch) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        f4 v;
-                        const f4 rv = rres[r][i];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[j] = o[i][j] * sc + sh + rv[j];
-                            if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
-                            if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;   // cells off the board stay zero
-                        }
-                        __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
-                    }
-                }
-                if (r + 2 < 4) rload(r + 2);
+                if (!(ABL & 64) || v[0] == 123.456f) __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
             }
         }
-    };
-    if (half == 0) finish(std::integral_constant<int, 0>{});
-    else finish(std::integral_constant<int, 1>{});
+        if (r + 2 < 4) rload(r + 2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -435,7 +400,9 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
                 if (s + 1 < 16) aload(s + 1, k);
             }
         }
+#ifndef WINO_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
+#endif
         if (c + 1 < 8 && !(ABL & 2)) produce(c + 1);
         if (c + 2 < 8) {
             lstore(in_buf + (c & 1) * IN_BUF2);        // in_buf[c & 1]: V(c) was built in phase c - 1
@@ -509,8 +476,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
 
 }  // namespace
 
-// sprl_wino_weight_layout(): 1 = U2[p][s][kb][lane], 2 = U4[p / 4][s][kb][lane][p % 4] (what wino_transform must produce)
-extern "C" int sprl_wino_weight_layout(void) { return getenv("SPRL_WINO_V1") ? 1 : 2; }
+// sprl_wino_weight_layout(): 2 = U4[p / 4][s][kb][lane][p % 4] (what wino_transform must produce; 1 was U2[p][s][kb][lane])
+extern "C" int sprl_wino_weight_layout(void) { return 2; }
 
 // x, y, res: activations in layout W (4096 floats per board; res may be null; y must not alias x); u: 36*64*64 pre-transformed
 // weights in A-operand order (torch_eval.cpp: wino_transform); scale/shift: [64].  Returns 0, or -1 when the board shape has
@@ -527,7 +494,7 @@ extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float*
                                     float* y, int batch, int H, int W, int relu, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static const int version = getenv("SPRL_WINO_V1") ? 1 : 2;
+    static const int version = getenv("SPRL_WINO_V3") ? 3 : 2;
     static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
     if (version == 2) {
         const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
@@ -537,11 +504,10 @@ extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float*
         else return -1;
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
-    if (batch_dev) return -1;
     const dim3 grid((unsigned)((batch + NIMG - 1) / NIMG)), block(NTHR);
-    if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
-    else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
-    else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu);
+    if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
+    else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
+    else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -323,6 +323,7 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     be::dmemset(P.leaf_offset, 0, (size_t)P.num_slots * sizeof(uint32_t));
     be::dmemset(e->nn_logits, 0, nq * (size_t)e->g.A * sizeof(float));
     be::dmemset(e->nn_value, 0, nq * sizeof(float));
+    be::dmemset(P.counters, 0, sizeof(Counters));
     be::sync();
     *out = e;
     return 0;

@@ -11,9 +11,9 @@ static float run(const float* x, const float* u, const float* sc, const float* s
     hipEventCreate(&a);
     hipEventCreate(&b);
     dim3 grid((B + NIMG - 1) / NIMG), block(NTHR);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, nullptr);
     hipEventRecord(a, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, nullptr);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
     float ms = 0;
