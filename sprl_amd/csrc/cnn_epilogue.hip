@@ -211,7 +211,8 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
                                                    const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
                                                    const float* __restrict__ vfc2_b, float* __restrict__ logits,
                                                    float* __restrict__ value, int batch, int H, int W, int A, int HID,
-                                                   const unsigned* __restrict__ batch_dev) {
+                                                   const unsigned* __restrict__ batch_dev, const float* __restrict__ maps_in) {
+    // maps_in != null: the head maps [batch][OC * H * W] were already produced (by the last trunk convolution): FC layers only
     if (batch_dev) {
         const int real = (int)*batch_dev;
         batch = real < batch ? real : batch;
@@ -227,6 +228,13 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
     for (int i = tid; i < OC * 64 + OC; i += 256) s_hw[i] = i < OC * 64 ? hw[i] : hb[i - OC * 64];
     for (int i = tid; i < PIN * A; i += 256) s_pw[i] = pfc_w[i];
     for (int i = tid; i < VIN * HID; i += 256) s_vw[i] = vfc1_w[i];
+    if (maps_in) {
+        const int n_first = (int)blockIdx.x * TAIL_NB;
+        for (int i = tid; i < TAIL_NB * OC * HW; i += 256) {
+            const int bb = i / (OC * HW);
+            if (n_first + bb < batch) s_maps[bb][i - bb * (OC * HW)] = maps_in[(size_t)n_first * (OC * HW) + i];
+        }
+    }
     __syncthreads();
 
     // stage 1: thread = (board, row-in-tile i, tile): 4 cells x OC maps, all 64 channels
@@ -237,7 +245,7 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
     for (int o = 0; o < OC; ++o)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[o][j] = 0.0f;
-    if (n < batch) {
+    if (n < batch && !maps_in) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v* xp = (const f4v*)(x + (size_t)n * 4096 + i * 64 + tile * 4);
 #pragma unroll 4
@@ -261,7 +269,7 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
     for (int o = 0; o < OC; ++o)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (row < H && col0 + j < W) {
+            if (!maps_in && row < H && col0 + j < W) {
                 const float r = acc[o][j] + s_hw[OC * 64 + o];
                 s_maps[b][o * HW + row * W + col0 + j] = r > 0.0f ? r : 0.0f;
             }
@@ -343,19 +351,33 @@ extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* hw, const float* hb, const float* pfc_w,
+                            const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                            float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                            const unsigned* batch_dev, void* stream);
+
 // x: trunk output in layout W; hw/hb: [PC + VC][64] / [PC + VC] head convolutions (policy rows first); pfc_w: [PC*H*W][A]
 // (transposed Linear weight), vfc1_w: [VC*H*W][HID], vfc2_w: [HID]; logits: [batch][A], value: [batch].  -1: shape not covered.
 extern "C" int sprl_tail_heads_fc(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
                                   const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
                                   float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
                                   const unsigned* batch_dev, void* stream) {
+    return sprl_tail_fc(x, nullptr, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits, value, batch, H, W, PC, VC, A, HID,
+                        batch_dev, stream);
+}
+
+// maps_in != null: FC layers only, on head maps [batch][(PC + VC) * H * W] produced by sprl_wino_conv64_heads
+extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* hw, const float* hb, const float* pfc_w,
+                            const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                            float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                            const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     if (H > 8 || W > 8 || PC * H * W > TAIL_MAXIN || A > TAIL_MAXA || HID > TAIL_HID || VC * H * W > 64) return -1;
     const dim3 grid((unsigned)((batch + TAIL_NB - 1) / TAIL_NB)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (PC == 2 && VC == 1)
         hipLaunchKernelGGL((tail_kernel<2, 1>), grid, block, 0, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
-                           value, batch, H, W, A, HID, batch_dev);
+                           value, batch, H, W, A, HID, batch_dev, maps_in);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

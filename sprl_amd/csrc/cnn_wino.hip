@@ -274,17 +274,26 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
 // round sleeps once), so the prologue / output stage of one overlaps the MFMA phases of the other, and so does their HBM
 // traffic.  Same LDS images, V production, weight layout and activation layout as above.
 // ---------------------------------------------------------------------------------------------------
+// network tail fused into the last trunk convolution (TAIL = 1: 2 policy + 1 value head channels)
+struct TailArgs {
+    const float *hw, *hb, *pfc_w, *pfc_b, *vfc1_w, *vfc1_b, *vfc2_w, *vfc2_b;
+    float *logits, *value;
+    int A, HID;
+    float* maps_out;        // TAIL = 2: only the head maps [batch][3 * H * W] are written (the FC layers run in their own kernel)
+};
+
 constexpr int NIMG2 = 4, NTHR2 = 256;
 constexpr int CS2 = 449;                 // channel-slot stride for 4 boards (== 1 mod 32)
 constexpr int IN_BUF2 = 8 * CS2;
 constexpr int V_G2 = 36 * 64;            // V of one group: [p][c_sub][16 tiles]
 constexpr int LDS_FLOATS2 = 2 * IN_BUF2 + 4 * V_G2;      // 65.6 KB
 
-template <int H, int W, int ABL = 0>
+template <int H, int W, int ABL = 0, int TAIL = 0>
 __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                                   const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                                  int relu, int stagger, const unsigned* __restrict__ batch_dev) {
+                                                                  int relu, int stagger, const unsigned* __restrict__ batch_dev,
+                                                                  TailArgs ta) {
     // batch_dev != null: the number of boards is on the device (the engine's leaf count of this round), `batch` is the
     // capacity the grid was sized for; workgroups past the real count leave at once
     if (batch_dev) {
@@ -446,6 +455,16 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
     const int ty = tile >> 1, tx = tile & 1;
     rload(0);
     rload(1);
+    constexpr int OC = 3;                              // TAIL: 2 policy + 1 value head channels
+    float hp[TAIL ? OC : 1][4][4];                     // TAIL: this lane's share of the 1x1 head convolutions (its 4 channels)
+    if (TAIL) {
+#pragma unroll
+        for (int o = 0; o < OC; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hp[TAIL ? o : 0][i][j] = 0.0f;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         __builtin_amdgcn_sched_barrier(0);
@@ -456,6 +475,11 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
         inverse_transform(m, o);
         const int k = 16 * kb + 4 * c_sub + r;
         const float sc = scale[k], sh = shift[k];
+        float hwk[OC];
+        if (TAIL) {
+#pragma unroll
+            for (int oc = 0; oc < OC; ++oc) hwk[oc] = ta.hw[oc * 64 + k];
+        }
         if (n < batch) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -467,10 +491,75 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
                     if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                     if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;       // cells off the board stay zero
                 }
-                if (!(ABL & 64) || v[0] == 123.456f) __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
+                if (TAIL) {
+#pragma unroll
+                    for (int oc = 0; oc < OC; ++oc)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hp[TAIL ? oc : 0][i][j] += hwk[oc] * v[j];
+                } else if (!(ABL & 64) || v[0] == 123.456f) {
+                    __builtin_nontemporal_store(v, (f4*)(y + plane0 + (size_t)r * 256 + (size_t)i * 64));
+                }
             }
         }
         if (r + 2 < 4) rload(r + 2);
+    }
+    if (!TAIL) return;
+
+    // ---- fused tail (last trunk convolution only): head maps -> policy FC, value FC -> ReLU -> FC -> tanh ----
+    // The trunk output never goes to memory.  Every lane holds the head-convolution partial sums of its 4 channels for its
+    // 16 cells; the 16 partials of a cell (4 waves x 4 lane groups) are summed through LDS in a fixed order.
+    constexpr int PROW = OC * 256 + 16;                // partial row stride: 32 lanes of a bank group -> 32 banks
+    float* const part = lds;                           // [kb * 4 + c_sub][o][(i * 4 + j) * 16 + tl]
+    float* const maps = lds + 16 * PROW;               // [board][o * HW + row * W + col]
+    constexpr int HW = H * W;
+#pragma unroll
+    for (int oc = 0; oc < OC; ++oc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(kb * 4 + c_sub) * PROW + oc * 256 + (i * 4 + j) * 16 + tl] = hp[TAIL ? oc : 0][i][j];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < OC; ++q) {
+        const int idx = tid + NTHR2 * q;               // (o, cell) pairs: 768 per workgroup
+        const int oc = idx >> 8, cp = idx & 255;
+        float sum = 0.0f;
+#pragma unroll
+        for (int rw = 0; rw < 16; ++rw) sum += part[rw * PROW + oc * 256 + cp];
+        const int ij = cp >> 4, t16 = cp & 15;
+        const int b = t16 >> 2, tl4 = t16 & 3;
+        const int row = 4 * (tl4 >> 1) + (ij >> 2), col = 4 * (tl4 & 1) + (ij & 3);
+        sum += ta.hb[oc];
+        if (row < H && col < W) maps[b * (OC * HW) + oc * HW + row * W + col] = sum > 0.0f ? sum : 0.0f;
+    }
+    __syncthreads();
+    if (TAIL == 2) {
+        for (int i = tid; i < NIMG2 * OC * HW; i += NTHR2) {
+            const int b = i / (OC * HW);
+            if (n0 + b < batch) ta.maps_out[(size_t)n0 * (OC * HW) + i] = maps[i];
+        }
+        return;
+    }
+    {
+        const int b = wave, nb = n0 + b;               // one wave per board
+        const float* pm = maps + b * (OC * HW);        // policy maps [2 * HW], then the value map [HW]
+        const float* vm = pm + 2 * HW;
+        if (nb < batch) {
+            for (int a = lane; a < ta.A; a += 64) {
+                float sum = ta.pfc_b[a];
+                for (int q = 0; q < 2 * HW; ++q) sum += pm[q] * ta.pfc_w[q * ta.A + a];
+                ta.logits[(size_t)nb * ta.A + a] = sum;
+            }
+        }
+        float hsum = 0.0f;
+        if (lane < ta.HID) {
+            float h = ta.vfc1_b[lane];
+            for (int q = 0; q < HW; ++q) h += vm[q] * ta.vfc1_w[q * ta.HID + lane];
+            hsum = (h > 0.0f ? h : 0.0f) * ta.vfc2_w[lane];
+        }
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) hsum += __shfl_xor(hsum, msk, 64);
+        if (lane == 0 && nb < batch) ta.value[nb] = tanhf(hsum + ta.vfc2_b[0]);
     }
 }
 
@@ -498,9 +587,9 @@ extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float*
     static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
     if (version == 2) {
         const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
-        if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev);
-        else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev);
-        else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev);
+        if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev, TailArgs{});
+        else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev, TailArgs{});
+        else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev, TailArgs{});
         else return -1;
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
@@ -508,6 +597,47 @@ extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float*
     if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
     else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<6, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
     else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<7, 7>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
+    else return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// The last trunk convolution with the whole network tail fused behind it (2 policy + 1 value head channels): the trunk
+// output is never written; logits [batch][A] and value [batch] go straight to the caller's buffers.  hw/hb: [3][64] / [3]
+// head convolutions (policy rows first), pfc_w: [2*H*W][A], vfc1_w: [H*W][HID], vfc2_w: [HID].  -1: shape not covered.
+extern "C" int sprl_wino_conv64_tail(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                     int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
+                                     const float* pfc_w, const float* pfc_b, const float* vfc1_w, const float* vfc1_b,
+                                     const float* vfc2_w, const float* vfc2_b, float* logits, float* value, int A, int HID,
+                                     void* stream) {
+    if (batch <= 0) return 0;
+    if (HID > 64 || A < 1) return -1;
+    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
+    const TailArgs ta{ hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits, value, A, HID, nullptr };
+    const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
+    hipStream_t st = (hipStream_t)stream;
+    if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, 0, 1>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
+    else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7, 0, 1>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
+    else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7, 0, 1>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
+    else return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Same, but only the ReLU'd head maps [batch][3 * H * W] (policy maps first) are produced; the FC layers follow in
+// sprl_tail_fc (cnn_epilogue.hip), which keeps their weights in LDS for 16 boards at a time.
+extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                      int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
+                                      float* maps_out, void* stream) {
+    if (batch <= 0) return 0;
+    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
+    TailArgs ta{};
+    ta.hw = hw;
+    ta.hb = hb;
+    ta.maps_out = maps_out;
+    const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
+    hipStream_t st = (hipStream_t)stream;
+    if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, 0, 2>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
+    else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7, 0, 2>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
+    else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7, 0, 2>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

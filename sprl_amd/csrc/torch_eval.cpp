@@ -25,6 +25,18 @@ extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float*
 extern "C" int sprl_wino_weight_layout(void);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_wino_conv64_tail(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                     int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
+                                     const float* pfc_w, const float* pfc_b, const float* vfc1_w, const float* vfc1_b,
+                                     const float* vfc2_w, const float* vfc2_b, float* logits, float* value, int A, int HID,
+                                     void* stream);
+extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                      int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
+                                      float* maps_out, void* stream);
+extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* hw, const float* hb, const float* pfc_w,
+                            const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                            float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                            const unsigned* batch_dev, void* stream);
 extern "C" int sprl_tail_heads_fc(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
                                   const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
                                   float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
@@ -191,8 +203,40 @@ bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::T
         }
         return rc == 0;
     };
-    for (const auto& b : n.blocks) {
-        if (!conv(x, b.u1, b.s1, b.t1, nullptr, y) || !conv(y, b.u2, b.s2, b.t2, x.data_ptr<float>(), z)) return false;
+    const int A0 = (int)n.pfc_w.size(1), HID0 = (int)n.vfc1_w.size(1);
+    // the last convolution can carry the whole tail (heads + FC layers) behind its inverse transform
+    const bool fuse_last = logits_out && value_out && n.pc == 2 && n.vc == 1 && HID0 <= 64 && n.vfc2_w.numel() == HID0 &&
+                           !getenv("SPRL_TORCH_NO_CONV_TAIL");
+    for (size_t bi = 0; bi < n.blocks.size(); ++bi) {
+        const auto& b = n.blocks[bi];
+        if (!conv(x, b.u1, b.s1, b.t1, nullptr, y)) return false;
+        if (fuse_last && bi + 1 == n.blocks.size()) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+            if (timed) (void)hipEventRecord(e0, nullptr);
+            // last convolution + both head convolutions in one kernel (the trunk output is never written), then the FC layers
+            at::Tensor maps = at::empty({ B, (int64_t)3 * H * W }, opts);
+            const int rc = sprl_wino_conv64_heads(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(),
+                                                  b.t2.data_ptr<float>(), x.data_ptr<float>(), B, H, W, batch_dev,
+                                                  n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), maps.data_ptr<float>(),
+                                                  nullptr);
+            if (timed) {
+                (void)hipEventRecord(e1, nullptr);
+                prof->ev.push_back(e0);
+                prof->ev.push_back(e1);
+                prof->launches++;
+                prof->boards += B;
+            }
+            if (rc != 0) return false;
+            if (sprl_tail_fc(nullptr, maps.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
+                             n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
+                             n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A0, HID0,
+                             batch_dev, nullptr) != 0)
+                return false;
+            *wrote_outputs = true;
+            return true;
+        }
+        if (!conv(y, b.u2, b.s2, b.t2, x.data_ptr<float>(), z)) return false;
         std::swap(x, z);
     }
     const int HW = H * W;

@@ -27,9 +27,9 @@ static float run2(const float* x, const float* u, const float* sc, const float* 
     hipEventCreate(&a);
     hipEventCreate(&b);
     dim3 grid((B + NIMG2 - 1) / NIMG2), block(NTHR2);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger, nullptr);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger, nullptr, TailArgs{});
     hipEventRecord(a, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger, nullptr);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger, nullptr, TailArgs{});
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
     float ms = 0;
