@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--rounds-per-call", type=int, default=64)
+    ap.add_argument("--populations", type=int, default=1,
+                    help="split the resident games of a GPU into this many engines, each on its own HIP stream and host thread: "
+                         "one population's tree kernel and convolution tails overlap the other's CNN work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
@@ -154,12 +157,20 @@ def main():
                                    os.path.join(tmpdir, f"traced_bench_r{rank}.pt"), "othello")
     total_steps = args.steps + args.warmup
     # unique RNG streams for every game of every step of every rank
-    cfg = E.default_config("othello", lib, device=local_rank, concurrent_games=args.concurrent,
-                           num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
-                           stream_base=1 + rank * games * (total_steps + 1), profile=0 if args.no_profile else 1)
-    eng = E.Engine(cfg, lib)
+    pops = max(1, args.populations)
+    if args.concurrent % pops or games % pops:
+        raise SystemExit("--populations must divide --concurrent and --games")
+    engines = []
     t_load = time.perf_counter()
-    eng.set_model(model_path if model_path else args.model)
+    for p in range(pops):
+        cfg = E.default_config("othello", lib, device=local_rank, concurrent_games=args.concurrent // pops,
+                               num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
+                               stream_base=1 + (rank * pops + p) * (games // pops) * (total_steps + 2),
+                               profile=0 if args.no_profile else 1, own_stream=1 if pops > 1 else 0)
+        en = E.Engine(cfg, lib)
+        en.set_model(model_path if model_path else args.model)
+        engines.append(en)
+    eng = engines[0]
     t_load = time.perf_counter() - t_load
 
     def barrier():
@@ -177,24 +188,47 @@ def main():
         torch.cuda.synchronize()
         return sum(sh["total_plies"] for sh in shards) if shards is not None else rec.total_plies
 
-    def one_step():
-        eng.begin(games)
+    def play(en, n_games, out, k):
+        en.begin(n_games)
         done = 0
-        while done < games:
-            done, _ = eng.step(args.rounds_per_call)
-        rec = eng.collect()
-        plies = gather_records(rec)
-        rec.close()
+        while done < n_games:
+            done, _ = en.step(args.rounds_per_call)
+        out[k] = en.collect()
+
+    def one_step():
+        recs = [None] * pops
+        if pops == 1:
+            play(engines[0], games, recs, 0)
+        else:                                       # one host thread per population (the C calls release the GIL)
+            import threading
+            ths = [threading.Thread(target=play, args=(engines[k], games // pops, recs, k)) for k in range(pops)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        plies = 0
+        for rec in recs:
+            plies += gather_records(rec)
+            rec.close()
         return plies
 
-    # untimed primer: model load, MIOpen kernel selection, first-touch of the arenas
-    eng.begin(games)
-    eng.step(4)
+    # untimed primer: first-touch of the arenas
+    for en in engines:
+        en.begin(games // pops)
+        en.step(4)
     barrier()
 
     for _ in range(args.warmup):
         one_step()
-    st0 = eng.stats()
+    def all_stats():
+        tot = {}
+        for en in engines:
+            for k, v in en.stats().items():
+                if isinstance(v, (int, float)):
+                    tot[k] = max(tot.get(k, 0), v) if k in ("max_nodes_in_arena", "cyc_max_slot_launch") else tot.get(k, 0) + v
+        return tot
+
+    st0 = all_stats()
     barrier()
     t0 = time.perf_counter()
     plies = 0
@@ -206,7 +240,7 @@ def main():
         tt = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    st1 = eng.stats()
+    st1 = all_stats()
     d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
 
     if rank == 0:
@@ -227,7 +261,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic (start-position self-play, random-init weights)",
             "config": {"workload": f"Othello 8x8, {args.traversals} UCT iters/move, {args.concurrent} concurrent games/GPU, "
-                                   f"{games} games/GPU/step, batch 8/queue 4, D4, Dirichlet(0.25,0.3)",
+                                   f"{games} games/GPU/step, batch 8/queue 4, D4, Dirichlet(0.25,0.3)" +
+                                   (f", {pops} populations on {pops} HIP streams" if pops > 1 else ""),
                        "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32, " + eng.evaluator_info() if model_path else args.model),
                        "parallelism": f"game-sharded x{world}, RCCL gather of records" if world > 1 else "1 GPU"},
             "expansions_per_sec": d["expansions"] * world / elapsed,
@@ -291,7 +326,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {exc}"}
         print(json.dumps(out), flush=True)
-    eng.close()
+    for en in engines:
+        en.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -62,9 +62,13 @@ typedef struct sprl_config {
     int32_t node_cap;          /* nodes per game arena (1 KiB each), <= 65535; 0 = default */
     int32_t spare_arenas;      /* arenas kept free for compaction; 0 = default */
     int32_t max_plies;         /* record capacity per game; 0 = default */
-    uint64_t seed;             /* game g uses Random(seed, stream_base + g) (utils/random.hpp:92-103) */
+    uint64_t seed;             /* game g uses Random(seed, stream_base + g) (utils/random.hpp:92-103); a later run on the same
+                                  engine continues the numbering (its game g: stream_base + games of earlier runs + g) */
     int32_t stream_base;       /* must be >= 1 */
     int32_t profile;           /* 1: time every tree-kernel launch with HIP events on its stream */
+    int32_t own_stream;        /* 1: the engine works on a private non-blocking HIP stream instead of the null stream, so that
+                                  several engines driven from different host threads overlap on one GPU */
+    int32_t reserved_;
 } sprl_config;
 
 /* Fills `cfg` with the reference worker's constants for `game` (OTHWorker.cpp:24-28, C4Worker.cpp:23-27,

@@ -19,6 +19,12 @@ int h2d(void* dst, const void* src, size_t n);
 int d2h(void* dst, const void* src, size_t n);
 int dmemset(void* dst, int v, size_t n);
 int sync();
+// every operation above and below goes to the calling thread's current stream (null stream unless set)
+void* stream_create();
+void stream_destroy(void* s);
+void set_stream(void* s);
+void bind(int device, void* s);   // make `device` current on the calling thread and `s` its stream
+void* current_stream();
 // one 64-lane wavefront per game slot, on the null stream
 int launch_step(int game, const EngineParams& P);
 // match play: slots (pair, pair + num_slots/2) hold the two agents' trees of one game; Othello, Connect Four, Go 7x7

@@ -10,6 +10,7 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local hipStream_t g_stream = nullptr;   // the calling thread's engine stream (engine.cpp sets it at every API entry)
 
 bool ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
@@ -134,27 +135,46 @@ void* dmalloc(size_t bytes) {
 void dfree(void* p) {
     if (p) (void)hipFree(p);
 }
-int h2d(void* dst, const void* src, size_t n) { return ok(hipMemcpy(dst, src, n, hipMemcpyHostToDevice), "hipMemcpy h2d") ? 0 : -1; }
-int d2h(void* dst, const void* src, size_t n) { return ok(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost), "hipMemcpy d2h") ? 0 : -1; }
-int dmemset(void* dst, int v, size_t n) { return ok(hipMemsetAsync(dst, v, n, 0), "hipMemsetAsync") ? 0 : -1; }
-int sync() { return ok(hipStreamSynchronize(0), "hipStreamSynchronize") ? 0 : -1; }
+int h2d(void* dst, const void* src, size_t n) {
+    return ok(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, g_stream), "hipMemcpy h2d") && ok(hipStreamSynchronize(g_stream), "h2d sync") ? 0 : -1;
+}
+int d2h(void* dst, const void* src, size_t n) {
+    return ok(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, g_stream), "hipMemcpy d2h") && ok(hipStreamSynchronize(g_stream), "d2h sync") ? 0 : -1;
+}
+int dmemset(void* dst, int v, size_t n) { return ok(hipMemsetAsync(dst, v, n, g_stream), "hipMemsetAsync") ? 0 : -1; }
+int sync() { return ok(hipStreamSynchronize(g_stream), "hipStreamSynchronize") ? 0 : -1; }
+void* stream_create() {
+    hipStream_t s = nullptr;
+    if (!ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    return (void*)s;
+}
+void stream_destroy(void* s) {
+    if (s) (void)hipStreamDestroy((hipStream_t)s);
+}
+void set_stream(void* s) { g_stream = (hipStream_t)s; }
+void bind(int device, void* s) {
+    static thread_local int bound = -1;
+    if (bound != device && hipSetDevice(device) == hipSuccess) bound = device;
+    g_stream = (hipStream_t)s;
+}
+void* current_stream() { return (void*)g_stream; }
 
 int launch_step(int game, const EngineParams& P) {
     dim3 grid((unsigned)P.num_slots), block(64);
-    if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(step_kernel<Othello>, grid, block, 0, 0, P);
-    else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(step_kernel<Go7>, grid, block, 0, 0, P);
-    else if (game == SPRL_GAME_GO9) hipLaunchKernelGGL(step_kernel_wide<GoN<9>>, grid, block, 0, 0, P);
-    else if (game == SPRL_GAME_GO19) hipLaunchKernelGGL(step_kernel_wide<GoN<19>>, grid, block, 0, 0, P);
-    else if (game == SPRL_GAME_GO7W) hipLaunchKernelGGL(step_kernel_wide<GoN<7>>, grid, block, 0, 0, P);
-    else hipLaunchKernelGGL(step_kernel<ConnectFour>, grid, block, 0, 0, P);
+    if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(step_kernel<Othello>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(step_kernel<Go7>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO9) hipLaunchKernelGGL(step_kernel_wide<GoN<9>>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO19) hipLaunchKernelGGL(step_kernel_wide<GoN<19>>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO7W) hipLaunchKernelGGL(step_kernel_wide<GoN<7>>, grid, block, 0, g_stream, P);
+    else hipLaunchKernelGGL(step_kernel<ConnectFour>, grid, block, 0, g_stream, P);
     return ok(hipGetLastError(), "step_kernel launch") ? 0 : -1;
 }
 
 int launch_match(int game, const EngineParams& P) {
     dim3 grid((unsigned)P.num_slots), block(64);
-    if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(match_kernel<Othello>, grid, block, 0, 0, P);
-    else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(match_kernel<Go7>, grid, block, 0, 0, P);
-    else if (game == SPRL_GAME_CONNECT_FOUR) hipLaunchKernelGGL(match_kernel<ConnectFour>, grid, block, 0, 0, P);
+    if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(match_kernel<Othello>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(match_kernel<Go7>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_CONNECT_FOUR) hipLaunchKernelGGL(match_kernel<ConnectFour>, grid, block, 0, g_stream, P);
     else {
         g_err = "match play is built for Othello, Connect Four and Go 7x7";
         return -1;
@@ -163,15 +183,15 @@ int launch_match(int game, const EngineParams& P) {
 }
 
 int launch_compact(const EngineParams& P, int floats_per_leaf) {
-    hipLaunchKernelGGL(leaf_scan_kernel, dim3(1), dim3(1024), 0, 0, P.leaf_count, P.leaf_offset, P.counters, P.num_slots);
-    hipLaunchKernelGGL(leaf_gather_kernel, dim3((unsigned)P.num_slots), dim3(64), 0, 0, P, floats_per_leaf);
+    hipLaunchKernelGGL(leaf_scan_kernel, dim3(1), dim3(1024), 0, g_stream, P.leaf_count, P.leaf_offset, P.counters, P.num_slots);
+    hipLaunchKernelGGL(leaf_gather_kernel, dim3((unsigned)P.num_slots), dim3(64), 0, g_stream, P, floats_per_leaf);
     return ok(hipGetLastError(), "leaf compaction launch") ? 0 : -1;
 }
 
 void* mark() {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    (void)hipEventRecord(e, 0);
+    (void)hipEventRecord(e, g_stream);
     return (void*)e;
 }
 double elapsed_ms(void* a, void* b) {

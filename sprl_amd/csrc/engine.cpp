@@ -79,7 +79,7 @@ struct TorchPlugin {
     int (*forward)(void*, const float*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
     void (*release)(void*) = nullptr;
     int (*is_native)(void*) = nullptr;
-    int (*forward_dev)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
+    int (*forward_dev)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int) = nullptr;
     void (*profile_enable)(void*, int) = nullptr;
     void (*profile_read)(void*, double*, int64_t*, int64_t*) = nullptr;
 };
@@ -111,6 +111,8 @@ struct sprl_engine {
     int64_t rounds = 0, launches = 0, nn_batches = 0, nn_rows = 0;
     int nn_bucket = 1024;
     bool nn_bucket_set = false;
+    int64_t games_begun = 0;    // games of earlier runs on this engine: a later run continues with fresh RNG streams
+    void* stream = nullptr;     // private non-blocking stream (cfg.own_stream) or null = the null stream
     bool dev_batch = false;     // the evaluator takes the batch size from device memory: rounds are enqueued without a host sync
     unsigned long long last_leaf_rows = 0;
     double seconds = 0.0, kernel_ms = 0.0, nn_ms = 0.0;
@@ -158,7 +160,7 @@ int load_torch_plugin(sprl_engine* e) {
     e->torch.forward = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, char*, int))dlsym(lib, "sprl_torch_forward");
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
     e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
-    e->torch.forward_dev = (int (*)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, char*, int))dlsym(
+    e->torch.forward_dev = (int (*)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int))dlsym(
         lib, "sprl_torch_forward_dev");
     e->torch.profile_enable = (void (*)(void*, int))dlsym(lib, "sprl_torch_profile_enable");
     e->torch.profile_read = (void (*)(void*, double*, int64_t*, int64_t*))dlsym(lib, "sprl_torch_profile_read");
@@ -181,6 +183,8 @@ int load_network(sprl_engine* e, const char* model, void** out) {
     const int bucket = kind == 2 ? 64 : 1024;
     if (bucket > e->nn_bucket || !e->nn_bucket_set) e->nn_bucket = bucket;
     e->nn_bucket_set = true;
+    void* const saved_stream = be::current_stream();
+    be::set_stream(nullptr);                     // the plain forward works on the null stream
     const int max_rows = e->P.num_slots * e->P.max_queue;
     const int step_rows = kind == 2 ? (max_rows > 4096 ? max_rows / 4 : max_rows) : e->nn_bucket;
     int last = 0;
@@ -191,11 +195,13 @@ int load_network(sprl_engine* e, const char* model, void** out) {
         if (e->torch.forward(m, e->P.nn_dense, b, e->g.planes, e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, err,
                              (int)sizeof(err)) != 0) {
             e->torch.release(m);
+            be::set_stream(saved_stream);
             return fail(SPRL_E_MODEL, std::string("network warm-up forward failed: ") + err);
         }
         if (b == max_rows) break;
     }
     be::sync();
+    be::set_stream(saved_stream);
     *out = m;
     return 0;
 }
@@ -265,6 +271,14 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
 
     sprl_engine* e = new sprl_engine();
     e->cfg = *cfg;
+    if (cfg->own_stream) {
+        e->stream = be::stream_create();
+        if (!e->stream) {
+            delete e;
+            return fail(SPRL_E_DEVICE, std::string("cannot create a HIP stream (") + be::last_error() + ")");
+        }
+    }
+    be::bind(e->cfg.device, e->stream);
     e->g = geom_of(cfg->game);
     EngineParams& P = e->P;
     memset(&P, 0, sizeof(P));
@@ -331,14 +345,19 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
 
 void sprl_engine_destroy(sprl_engine* e) {
     if (!e) return;
+    be::bind(e->cfg.device, e->stream);
+    be::sync();
     resolve_marks(e);
     if (e->torch_model && e->torch.release) e->torch.release(e->torch_model);
     for (void* p : e->allocs) be::dfree(p);
+    if (e->stream) be::stream_destroy(e->stream);
+    be::set_stream(nullptr);
     delete e;
 }
 
 int sprl_engine_set_model(sprl_engine* e, const char* model) {
     if (!e || !model) return fail(SPRL_E_CONFIG, "null argument");
+    be::bind(e->cfg.device, e->stream);
     if (e->running) return fail(SPRL_E_STATE, "cannot change the evaluator while a run is in progress");
     e->dev_batch = false;
     if (strcmp(model, "random") == 0) {          // GridWorker.hpp:36-38,125-127
@@ -359,8 +378,14 @@ int sprl_engine_set_model(sprl_engine* e, const char* model) {
         char perr[256] = { 0 };
         e->dev_batch = e->torch.forward_dev && !getenv("SPRL_SYNC_ROUNDS") &&
                        e->torch.forward_dev(m, e->P.nn_dense, &e->P.counters->leaf_total, e->P.num_slots * e->P.max_queue, e->g.planes,
-                                            e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, perr, (int)sizeof(perr)) == 0;
+                                            e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, e->stream, perr, (int)sizeof(perr)) == 0;
         be::sync();
+    }
+    if (e->stream && !e->dev_batch) {
+        e->torch.release(m);
+        e->torch_model = nullptr;
+        return fail(SPRL_E_CONFIG, "own_stream needs an evaluator that runs on the engine's stream: the hand-written CNN path "
+                                   "(reference architecture, 64-channel trunk) or an in-kernel evaluator");
     }
     if (e->cfg.profile && e->torch.profile_enable) e->torch.profile_enable(m, 1);
     e->forward_cb = nullptr;
@@ -384,6 +409,7 @@ int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len) {
 
 int sprl_engine_set_forward(sprl_engine* e, sprl_forward_fn fn, void* user) {
     if (!e || !fn) return fail(SPRL_E_CONFIG, "null argument");
+    if (e->stream) return fail(SPRL_E_CONFIG, "a forward hook works on the null stream: not available with own_stream");
     if (e->running) return fail(SPRL_E_STATE, "cannot change the evaluator while a run is in progress");
     e->forward_cb = fn;
     e->forward_user = user;
@@ -393,6 +419,7 @@ int sprl_engine_set_forward(sprl_engine* e, sprl_forward_fn fn, void* user) {
 
 int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
     if (!e) return fail(SPRL_E_CONFIG, "null engine");
+    be::bind(e->cfg.device, e->stream);
     if (num_games < 1) return fail(SPRL_E_CONFIG, "num_games must be >= 1");
     EngineParams& P = e->P;
     // (re)allocate record buffers for this run
@@ -409,6 +436,8 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
     }
     e->num_games = num_games;
     e->last_leaf_rows = 0;
+    P.stream_base = e->cfg.stream_base + (int32_t)e->games_begun;   // run k's game g: stream_base + games of runs < k + g
+    e->games_begun += num_games;
     P.num_games = num_games;
     P.eval_kind = e->eval_kind;
     std::vector<GameCtl> ctl((size_t)P.num_slots);
@@ -437,6 +466,7 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
 
 int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_t* active_slots) {
     if (!e) return fail(SPRL_E_CONFIG, "null engine");
+    be::bind(e->cfg.device, e->stream);
     if (!e->running) return fail(SPRL_E_STATE, "sprl_engine_begin has not been called");
     if (rounds < 1) rounds = 1;
     EngineParams& P = e->P;
@@ -468,7 +498,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
                 void* n0 = e->cfg.profile ? be::mark() : nullptr;
                 char err[512] = { 0 };
                 if (e->torch.forward_dev(e->torch_model, P.nn_dense, &P.counters->leaf_total, max_batch_rows, e->g.planes, e->g.rows,
-                                         e->g.cols, e->nn_logits, e->g.A, e->nn_value, err, (int)sizeof(err)) != 0) {
+                                         e->g.cols, e->nn_logits, e->g.A, e->nn_value, e->stream, err, (int)sizeof(err)) != 0) {
                     e->running = false;
                     return fail(SPRL_E_MODEL, std::string("network forward failed: ") + err);
                 }
@@ -530,6 +560,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
 
 int sprl_engine_collect(sprl_engine* e, sprl_records* out) {
     if (!e || !out) return fail(SPRL_E_CONFIG, "null argument");
+    be::bind(e->cfg.device, e->stream);
     if (!e->running) return fail(SPRL_E_STATE, "no run in progress");
     EngineParams& P = e->P;
     const Geom& g = e->g;
@@ -745,6 +776,7 @@ void sprl_records_free(sprl_records* r) {
 
 int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
     if (!e || !out) return fail(SPRL_E_CONFIG, "null argument");
+    be::bind(e->cfg.device, e->stream);
     memset(out, 0, sizeof(*out));
     resolve_marks(e);
     std::vector<GameCtl> ctl((size_t)e->P.num_slots);

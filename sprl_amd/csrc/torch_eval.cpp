@@ -82,6 +82,7 @@ struct Model {
     int device = 0;
     NativeNet native;
     ConvProfile prof;
+    at::Tensor act[3], maps;     // activation buffers of the hand-written path, kept across calls (no allocator traffic, any stream)
 };
 
 // scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta  (BatchNorm2d eval, eps = 1e-5)
@@ -178,23 +179,29 @@ bool epilogue(at::Tensor& x, const at::Tensor& scale, const at::Tensor& shift, c
 
 // Trunk entirely in hand-written kernels: stem (VALU) -> residual blocks (Winograd on fp32 MFMA, cnn_wino.hip) -> both
 // 1x1 heads, activations in layout W; only the three small fully connected layers go through the BLAS library.
-bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::Tensor& v, ConvProfile* prof, float* logits_out,
-                  float* value_out, bool* wrote_outputs, const unsigned* batch_dev = nullptr) {
+bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v, ConvProfile* prof, float* logits_out,
+                  float* value_out, bool* wrote_outputs, const unsigned* batch_dev = nullptr, void* stream = nullptr) {
+    const NativeNet& n = mdl->native;
     const int B = (int)in.size(0), P = (int)in.size(1), H = (int)in.size(2), W = (int)in.size(3);
     auto opts = in.options();
-    at::Tensor x = at::empty({ B, 4096 }, opts), y = at::empty({ B, 4096 }, opts), z = at::empty({ B, 4096 }, opts);
+    if (!mdl->act[0].defined() || mdl->act[0].size(0) < B) {
+        for (auto& t : mdl->act) t = at::empty({ B, 4096 }, opts);
+        mdl->maps = at::empty({ B, (int64_t)3 * 64 }, opts);
+        (void)hipDeviceSynchronize();            // the buffers may be used on another stream than the one that allocated them
+    }
+    at::Tensor x = mdl->act[0], y = mdl->act[1], z = mdl->act[2];
     if (sprl_stem_conv3x3_w(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
-                            n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, batch_dev, nullptr) != 0)
+                            n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, batch_dev, stream) != 0)
         return false;
     auto conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
                     at::Tensor& dst) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-        if (timed) (void)hipEventRecord(e0, nullptr);
+        if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
         const int rc = sprl_wino_conv64_dev(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(),
-                                            res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, nullptr);
+                                            res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, stream);
         if (timed) {
-            (void)hipEventRecord(e1, nullptr);
+            (void)hipEventRecord(e1, (hipStream_t)stream);
             prof->ev.push_back(e0);
             prof->ev.push_back(e1);
             prof->launches++;
@@ -213,15 +220,15 @@ bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::T
         if (fuse_last && bi + 1 == n.blocks.size()) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-            if (timed) (void)hipEventRecord(e0, nullptr);
+            if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
             // last convolution + both head convolutions in one kernel (the trunk output is never written), then the FC layers
-            at::Tensor maps = at::empty({ B, (int64_t)3 * H * W }, opts);
+            at::Tensor maps = mdl->maps;
             const int rc = sprl_wino_conv64_heads(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(),
                                                   b.t2.data_ptr<float>(), x.data_ptr<float>(), B, H, W, batch_dev,
                                                   n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), maps.data_ptr<float>(),
-                                                  nullptr);
+                                                  stream);
             if (timed) {
-                (void)hipEventRecord(e1, nullptr);
+                (void)hipEventRecord(e1, (hipStream_t)stream);
                 prof->ev.push_back(e0);
                 prof->ev.push_back(e1);
                 prof->launches++;
@@ -231,7 +238,7 @@ bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::T
             if (sprl_tail_fc(nullptr, maps.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
                              n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
                              n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A0, HID0,
-                             batch_dev, nullptr) != 0)
+                             batch_dev, stream) != 0)
                 return false;
             *wrote_outputs = true;
             return true;
@@ -245,24 +252,25 @@ bool forward_wino(const NativeNet& n, const at::Tensor& in, at::Tensor& p, at::T
         sprl_tail_heads_fc(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(),
                            n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
                            n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A,
-                           HID, batch_dev, nullptr) == 0) {
+                           HID, batch_dev, stream) == 0) {
         *wrote_outputs = true;                   // heads + FC layers fused, results already in the caller's buffers
         return true;
     }
-    if (batch_dev) return false;                 // the device-side count needs the fused tail
+    if (batch_dev || stream) return false;       // the device-side count / a private stream need the fused tail
     p = at::empty({ B, (int64_t)n.pc * HW }, opts);
     v = at::empty({ B, (int64_t)n.vc * HW }, opts);
     return sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
                                    p.data_ptr<float>(), v.data_ptr<float>(), B, 64, HW, n.pc, n.vc, W, nullptr) == 0;
 }
 
-bool forward_native(const NativeNet& n, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
+bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
                     float* logits_out, float* value_out, bool* wrote_outputs) {
+    const NativeNet& n = mdl->native;
     at::Tensor p, v;
     const int H0 = (int)in.size(2), W0 = (int)in.size(3), P0 = (int)in.size(1);
     const bool wino = n.wino && (P0 == 3 || P0 == 17) && ((H0 == 8 && W0 == 8) || (H0 == 6 && W0 == 7) || (H0 == 7 && W0 == 7));
     if (wino) {
-        if (!forward_wino(n, in, p, v, prof, logits_out, value_out, wrote_outputs)) return false;
+        if (!forward_wino(mdl, in, p, v, prof, logits_out, value_out, wrote_outputs)) return false;
         if (*wrote_outputs) return true;
     } else {
         at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
@@ -375,7 +383,7 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
         at::Tensor lo, va;
         bool wrote = false;
         const bool fuse_tail = m->device >= 0 && m->native.ok && m->native.pfc_w.size(1) == actions && !getenv("SPRL_TORCH_NO_FUSED_TAIL");
-        if (m->native.ok && forward_native(m->native, in, lo, va, &m->prof, fuse_tail ? logits : nullptr,
+        if (m->native.ok && forward_native(m, in, lo, va, &m->prof, fuse_tail ? logits : nullptr,
                                            fuse_tail ? value : nullptr, &wrote) && wrote)
             return 0;
         if (!lo.defined()) {
@@ -411,9 +419,10 @@ void sprl_torch_profile_read(void* handle, double* conv_ms, int64_t* launches, i
 
 // The whole forward with the batch size read ON THE DEVICE (`batch_dev`, <= max_batch): nothing here depends on the host
 // knowing how many leaves the round queued, so the engine can enqueue rounds without a synchronisation in between.
+// `stream`: the HIP stream every kernel of the forward goes to (null = the null stream).
 // Only the hand-written path (kind 2 with the fused tail) can do this; returns -2 when it cannot.
 int sprl_torch_forward_dev(void* handle, const float* planes, const unsigned* batch_dev, int max_batch, int nplanes, int rows,
-                           int cols, float* logits, int actions, float* value, char* err, int errlen) {
+                           int cols, float* logits, int actions, float* value, void* stream, char* err, int errlen) {
     try {
         auto* m = static_cast<Model*>(handle);
         const NativeNet& n = m->native;
@@ -425,7 +434,7 @@ int sprl_torch_forward_dev(void* handle, const float* planes, const unsigned* ba
         auto in = torch::from_blob(const_cast<float*>(planes), { max_batch, nplanes, rows, cols }, opts);
         at::Tensor p, v;
         bool wrote = false;
-        if (!forward_wino(n, in, p, v, &m->prof, logits, value, &wrote, batch_dev) || !wrote) return -2;
+        if (!forward_wino(m, in, p, v, &m->prof, logits, value, &wrote, batch_dev, stream) || !wrote) return -2;
         return 0;
     } catch (const std::exception& e) {
         put_err(err, errlen, e.what());

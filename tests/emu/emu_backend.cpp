@@ -50,6 +50,11 @@ int h2d(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return 0; }
 int d2h(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return 0; }
 int dmemset(void* dst, int v, size_t n) { memset(dst, v, n); return 0; }
 int sync() { return 0; }
+void* stream_create() { return nullptr; }
+void stream_destroy(void*) {}
+void set_stream(void*) {}
+void bind(int, void*) {}
+void* current_stream() { return nullptr; }
 int launch_step(int game, const EngineParams& P) {
     EngineParams copy = P;
     if (game == SPRL_GAME_OTHELLO) emu::launch(block_entry<Othello>, &copy, P.num_slots);

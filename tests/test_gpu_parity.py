@@ -275,3 +275,47 @@ def test_match_traced_models(lib, traced_model, tmp_path):
     assert sum(E.match_score(w)) == 48
     for g in range(48):                      # replay every game with the oracle's rules: every move legal, same end
         assert po.replay_winner(po.GAME_OTHELLO, actions[g, :n[g]]) == w[g]
+
+
+# ---- engines on private HIP streams, driven from several host threads ----
+
+def test_two_engines_on_private_streams_random_evaluator(lib):
+    """Two engines, own_stream=1, one host thread each, running at the same time: both bit-exact against the oracle."""
+    import threading
+    out = {}
+
+    def work(k, seed):
+        cfg = E.default_config("othello", lib, concurrent_games=64, num_traversals=48, seed=seed, stream_base=1 + 1000 * k,
+                               own_stream=1)
+        eng = E.Engine(cfg, lib)
+        eng.set_model("random")
+        out[k] = (cfg, eng.run(64), eng.stats())
+        eng.close()
+
+    ths = [threading.Thread(target=work, args=(k, 11 + k)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in range(2):
+        cfg, rec, st = out[k]
+        ora = po.selfplay(parity.oracle_config("othello", cfg, po.EVAL_RANDOM), 64, 11 + k, cfg.stream_base, True)
+        parity.assert_same_games(rec, ora)
+        parity.assert_same_counters(st, ora["stats"])
+
+
+def test_private_stream_cnn_games_equal_null_stream_games(lib, traced_model):
+    """The hand-written CNN gives every board the same bits whatever batch it sits in, so an engine on a private stream
+    (rounds enqueued without host synchronisation) plays exactly the games of an engine on the null stream."""
+    recs = []
+    for own in (0, 1):
+        cfg = E.default_config("othello", lib, concurrent_games=32, num_traversals=40, seed=5, own_stream=own)
+        eng = E.Engine(cfg, lib)
+        eng.set_model(traced_model)
+        rec = eng.run(32)
+        recs.append((rec.expand_boards(), rec.expand()))
+        eng.close()
+    (b0, p0), (s0, d0, o0) = recs[0]
+    (b1, p1), (s1, d1, o1) = recs[1]
+    assert (b0 == b1).all() and (p0 == p1).all() and (o0 == o1).all()
+    assert (d0.view(np.uint32) == d1.view(np.uint32)).all()
