@@ -270,8 +270,8 @@ __global__ void __launch_bounds__(NTHR) wino_conv64_kernel(const float* __restri
 // Version 2: 4 waves = 4 boards = 16 tiles per workgroup, TWO workgroups per CU.
 // Wave kb owns output channels 16kb..16kb+15 for ALL 36 transform positions of the 16 tiles (36 accumulator tiles,
 // 144 registers), so a lane ends the K loop holding every position of its four (channel, tile) pairs and the inverse
-// transform needs no exchange.  The two resident workgroups of a CU run half a period apart (the second one of the first
-// round sleeps once), so the prologue / output stage of one overlaps the MFMA phases of the other, and so does their HBM
+// transform needs no exchange.  The two resident workgroups of a CU drift out of phase, so the prologue / output stage of one
+// overlaps the MFMA phases of the other (`stagger` can force an offset in the first round; off by default), and so does their HBM
 // traffic.  Same LDS images, V production, weight layout and activation layout as above.
 // ---------------------------------------------------------------------------------------------------
 // network tail fused into the last trunk convolution (TAIL = 1: 2 policy + 1 value head channels)
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
 
     for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;    // borders stay zero for the whole kernel
 
-    // first round only: the workgroup in the second wave slot of its SIMD starts half a period late
+    // optional, first round only: the workgroup in the second wave slot of its SIMD starts `stagger` sleeps late
     if (stagger > 0 && (int)blockIdx.x < 2 * 256) {
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_ID.WAVE_ID
         if (slot & 1u)
@@ -584,7 +584,7 @@ extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float*
     if (batch <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     static const int version = getenv("SPRL_WINO_V3") ? 3 : 2;
-    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
+    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 0;
     if (version == 2) {
         const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
         if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, stagger, batch_dev, TailArgs{});
@@ -611,7 +611,7 @@ extern "C" int sprl_wino_conv64_tail(const float* x, const float* u, const float
                                      void* stream) {
     if (batch <= 0) return 0;
     if (HID > 64 || A < 1) return -1;
-    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
+    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 0;
     const TailArgs ta{ hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits, value, A, HID, nullptr };
     const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
     hipStream_t st = (hipStream_t)stream;
@@ -628,7 +628,7 @@ extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const floa
                                       int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
                                       float* maps_out, void* stream) {
     if (batch <= 0) return 0;
-    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 6;
+    static const int stagger = getenv("SPRL_WINO_STAGGER") ? atoi(getenv("SPRL_WINO_STAGGER")) : 0;
     TailArgs ta{};
     ta.hw = hw;
     ta.hb = hb;

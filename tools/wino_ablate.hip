@@ -11,7 +11,7 @@ static float run(const float* x, const float* u, const float* sc, const float* s
     hipEventCreate(&a);
     hipEventCreate(&b);
     dim3 grid((B + NIMG - 1) / NIMG), block(NTHR);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, nullptr);
+    for (int i = 0; i < 12; ++i) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, nullptr);
     hipEventRecord(a, 0);
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, nullptr);
     hipEventRecord(b, 0);
@@ -27,7 +27,7 @@ static float run2(const float* x, const float* u, const float* sc, const float* 
     hipEventCreate(&a);
     hipEventCreate(&b);
     dim3 grid((B + NIMG2 - 1) / NIMG2), block(NTHR2);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger, nullptr, TailArgs{});
+    for (int i = 0; i < 12; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger, nullptr, TailArgs{});
     hipEventRecord(a, 0);
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wino_conv64_v2_kernel<8, 8, ABL>), grid, block, 0, 0, x, u, sc, sh, res, y, B, 1, stagger, nullptr, TailArgs{});
     hipEventRecord(b, 0);
@@ -51,17 +51,17 @@ int main(int argc, char** argv) {
     hipMemcpy(sc, h.data(), 256, hipMemcpyHostToDevice);
     hipMemcpy(sh, h.data(), 256, hipMemcpyHostToDevice);
     printf("batch %d, us per launch\n", B);
-    for (int sg = 6; sg <= 6; sg += 2) printf("v2 full, stagger %d            %8.1f\n", sg, run2<0>(x, u, sc, sh, r, y, B, 20, sg));
-    printf("v2 no residual               %8.1f\n", run2<0>(x, u, sc, sh, nullptr, y, B, 20, 6));
-    printf("v2 no stores                 %8.1f\n", run2<64>(x, u, sc, sh, r, y, B, 20, 6));
-    printf("v2 no stores, no residual    %8.1f\n", run2<64>(x, u, sc, sh, nullptr, y, B, 20, 6));
-    printf("v2 no output stage           %8.1f\n", run2<1>(x, u, sc, sh, r, y, B, 20, 4));
-    printf("v2 no V production           %8.1f\n", run2<2>(x, u, sc, sh, r, y, B, 20, 4));
-    printf("v2 no weight loads           %8.1f\n", run2<4>(x, u, sc, sh, r, y, B, 20, 4));
-    printf("v2 weights from 8 KB footprint %8.1f\n", run2<32>(x, u, sc, sh, r, y, B, 20, 6));
-    printf("v2 no output, tiny-footprint wts %6.1f\n", run2<33>(x, u, sc, sh, r, y, B, 20, 6));
-    printf("v2 no output, no V, no wts   %8.1f\n", run2<7>(x, u, sc, sh, r, y, B, 20, 4));
-    printf("v2 skeleton + MFMA           %8.1f\n", run2<23>(x, u, sc, sh, r, y, B, 20, 4));
+    for (int sg = 0; sg <= 6; sg += 3) printf("v2 full, stagger %d            %8.1f\n", sg, run2<0>(x, u, sc, sh, r, y, B, 20, sg));
+    printf("v2 no residual               %8.1f\n", run2<0>(x, u, sc, sh, nullptr, y, B, 20, 0));
+    printf("v2 no stores                 %8.1f\n", run2<64>(x, u, sc, sh, r, y, B, 20, 0));
+    printf("v2 no stores, no residual    %8.1f\n", run2<64>(x, u, sc, sh, nullptr, y, B, 20, 0));
+    printf("v2 no output stage           %8.1f\n", run2<1>(x, u, sc, sh, r, y, B, 20, 0));
+    printf("v2 no V production           %8.1f\n", run2<2>(x, u, sc, sh, r, y, B, 20, 0));
+    printf("v2 no weight loads           %8.1f\n", run2<4>(x, u, sc, sh, r, y, B, 20, 0));
+    printf("v2 weights from 8 KB footprint %8.1f\n", run2<32>(x, u, sc, sh, r, y, B, 20, 0));
+    printf("v2 no output, tiny-footprint wts %6.1f\n", run2<33>(x, u, sc, sh, r, y, B, 20, 0));
+    printf("v2 no output, no V, no wts   %8.1f\n", run2<7>(x, u, sc, sh, r, y, B, 20, 0));
+    printf("v2 skeleton + MFMA           %8.1f\n", run2<23>(x, u, sc, sh, r, y, B, 20, 0));
     printf("full                         %8.1f\n", run<0>(x, u, sc, sh, r, y, B, 20));
     printf("no output stage              %8.1f\n", run<1>(x, u, sc, sh, r, y, B, 20));
     printf("no V production              %8.1f\n", run<2>(x, u, sc, sh, r, y, B, 20));
