@@ -100,7 +100,7 @@ def cpu_baseline(model_path, traversals, budget_games_per_core=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--games", type=int, default=0, help="games per GPU per step (default: = --concurrent)")
     ap.add_argument("--concurrent", type=int, default=4096, help="resident game slots per GPU")
@@ -188,6 +188,8 @@ def main():
         torch.cuda.synchronize()
         return sum(sh["total_plies"] for sh in shards) if shards is not None else rec.total_plies
 
+    gather_s = [0.0]
+
     def play(en, n_games, out, k):
         en.begin(n_games)
         done = 0
@@ -207,9 +209,11 @@ def main():
             for t in ths:
                 t.join()
         plies = 0
+        tg = time.perf_counter()
         for rec in recs:
             plies += gather_records(rec)
             rec.close()
+        gather_s[0] += time.perf_counter() - tg
         return plies
 
     # untimed primer: first-touch of the arenas
@@ -229,6 +233,7 @@ def main():
         return tot
 
     st0 = all_stats()
+    gather_s[0] = 0.0
     barrier()
     t0 = time.perf_counter()
     plies = 0
@@ -273,7 +278,8 @@ def main():
             "rank0": {"kernel_ms": d["kernel_ms"], "nn_ms": d["nn_ms"], "kernel_launches": d["kernel_launches"],
                       "rounds": d["rounds"], "nn_batches": d["nn_batches"], "nn_rows": d["nn_rows"],
                       "nn_fill": (d["nn_evals"] / d["nn_rows"]) if d["nn_rows"] else None, "hbm_gib": st1["hbm_bytes"] / 2**30, "model_load_and_warmup_s": t_load,
-                      "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"]},
+                      "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"],
+                      "record_gather_ms": 1000.0 * gather_s[0]},
         }
         if d.get("cyc_total", 0) > 0:
             out["phase_cycles_share"] = {k[4:]: d[k] / d["cyc_total"] for k in d if k.startswith("cyc_") and k not in ("cyc_total", "cyc_max_slot_launch")}
