@@ -111,6 +111,7 @@ struct sprl_engine {
     int64_t rounds = 0, launches = 0, nn_batches = 0, nn_rows = 0;
     int nn_bucket = 1024;
     bool nn_bucket_set = false;
+    sprl_stats carried{};       // slot counters of finished runs (the slots' own counters restart with every run)
     int64_t games_begun = 0;    // games of earlier runs on this engine: a later run continues with fresh RNG streams
     void* stream = nullptr;     // private non-blocking stream (cfg.own_stream) or null = the null stream
     bool dev_batch = false;     // the evaluator takes the batch size from device memory: rounds are enqueued without a host sync
@@ -204,6 +205,36 @@ int load_network(sprl_engine* e, const char* model, void** out) {
     be::set_stream(saved_stream);
     *out = m;
     return 0;
+}
+
+// per-slot search counters of the current run, added into `out`
+void add_slot_stats(const std::vector<GameCtl>& ctl, sprl_stats* out) {
+    for (const GameCtl& c : ctl) {
+        out->games += (int64_t)c.stats.games;
+        out->plies += (int64_t)c.stats.plies;
+        out->traversals += (int64_t)c.stats.traversals;
+        out->levels += (int64_t)c.stats.levels;
+        out->expansions += (int64_t)c.stats.expansions;
+        out->nn_evals += (int64_t)c.stats.nn_evals;
+        out->terminal_hits += (int64_t)c.stats.terminal_hits;
+        out->gray_hits += (int64_t)c.stats.gray_hits;
+        out->dup_hits += (int64_t)c.stats.dup_hits;
+        out->nodes_created += (int64_t)c.stats.nodes_created;
+        out->compactions += (int64_t)c.stats.compactions;
+        out->cyc_total += (int64_t)c.stats.cyc_total;
+        out->cyc_finish += (int64_t)c.stats.cyc_finish;
+        out->cyc_move += (int64_t)c.stats.cyc_move;
+        out->cyc_select += (int64_t)c.stats.cyc_select;
+        out->cyc_create += (int64_t)c.stats.cyc_create;
+        out->cyc_backup += (int64_t)c.stats.cyc_backup;
+        out->cyc_leafio += (int64_t)c.stats.cyc_leafio;
+        out->cyc_noise += (int64_t)c.stats.cyc_noise;
+        out->cyc_lvl_wait += (int64_t)c.stats.cyc_lvl_wait;
+        out->cyc_lvl_pick += (int64_t)c.stats.cyc_lvl_pick;
+        out->cyc_lvl_desc += (int64_t)c.stats.cyc_lvl_desc;
+        if ((int64_t)c.stats.cyc_max > out->cyc_max_slot_launch) out->cyc_max_slot_launch = (int64_t)c.stats.cyc_max;
+        if ((int64_t)c.stats.max_alloc > out->max_nodes_in_arena) out->max_nodes_in_arena = (int64_t)c.stats.max_alloc;
+    }
 }
 
 int check_device_error(sprl_engine* e, const Counters& c) {
@@ -433,6 +464,11 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
         ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
         ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
         if (!ok) return fail(SPRL_E_DEVICE, std::string("record allocation failed (") + be::last_error() + ")");
+    }
+    if (e->games_begun > 0) {                    // keep the search counters of the run that is being replaced
+        std::vector<GameCtl> old((size_t)P.num_slots);
+        if (be::sync() != 0 || be::d2h(old.data(), P.ctl, old.size() * sizeof(GameCtl)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+        add_slot_stats(old, &e->carried);
     }
     e->num_games = num_games;
     e->last_leaf_rows = 0;
@@ -782,32 +818,8 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
     std::vector<GameCtl> ctl((size_t)e->P.num_slots);
     if (be::sync() != 0 || be::d2h(ctl.data(), e->P.ctl, ctl.size() * sizeof(GameCtl)) != 0)
         return fail(SPRL_E_DEVICE, be::last_error());
-    for (const GameCtl& c : ctl) {
-        out->games += (int64_t)c.stats.games;
-        out->plies += (int64_t)c.stats.plies;
-        out->traversals += (int64_t)c.stats.traversals;
-        out->levels += (int64_t)c.stats.levels;
-        out->expansions += (int64_t)c.stats.expansions;
-        out->nn_evals += (int64_t)c.stats.nn_evals;
-        out->terminal_hits += (int64_t)c.stats.terminal_hits;
-        out->gray_hits += (int64_t)c.stats.gray_hits;
-        out->dup_hits += (int64_t)c.stats.dup_hits;
-        out->nodes_created += (int64_t)c.stats.nodes_created;
-        out->compactions += (int64_t)c.stats.compactions;
-        out->cyc_total += (int64_t)c.stats.cyc_total;
-        out->cyc_finish += (int64_t)c.stats.cyc_finish;
-        out->cyc_move += (int64_t)c.stats.cyc_move;
-        out->cyc_select += (int64_t)c.stats.cyc_select;
-        out->cyc_create += (int64_t)c.stats.cyc_create;
-        out->cyc_backup += (int64_t)c.stats.cyc_backup;
-        out->cyc_leafio += (int64_t)c.stats.cyc_leafio;
-        out->cyc_noise += (int64_t)c.stats.cyc_noise;
-        out->cyc_lvl_wait += (int64_t)c.stats.cyc_lvl_wait;
-        out->cyc_lvl_pick += (int64_t)c.stats.cyc_lvl_pick;
-        out->cyc_lvl_desc += (int64_t)c.stats.cyc_lvl_desc;
-        if ((int64_t)c.stats.cyc_max > out->cyc_max_slot_launch) out->cyc_max_slot_launch = (int64_t)c.stats.cyc_max;
-        if ((int64_t)c.stats.max_alloc > out->max_nodes_in_arena) out->max_nodes_in_arena = (int64_t)c.stats.max_alloc;
-    }
+    *out = e->carried;                           // finished runs on this engine
+    add_slot_stats(ctl, out);
     out->rounds = e->rounds;
     out->kernel_launches = e->launches;
     out->nn_batches = e->nn_batches;

@@ -235,3 +235,21 @@ def test_match_mixed_network_and_random(emu):
     agents = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="net", use_symmetry=True, parent_q=False)]
     parity.check_match(emu, "c4", agents, 4, concurrent_games=3, num_traversals=30, forwards=(None, engine_forward),
                        oracle_forwards=(None, cb))
+
+
+def test_second_run_on_one_engine_continues_streams_and_counters(emu):
+    """Run k on an engine plays games with streams stream_base + (games of earlier runs) + g; stats() covers all runs."""
+    cfg = E.default_config("c4", emu, concurrent_games=2, num_traversals=30, seed=21, stream_base=5)
+    eng = E.Engine(cfg, emu)
+    eng.set_model("random")
+    ocfg = parity.oracle_config("c4", cfg, po.EVAL_RANDOM)
+    rec1 = eng.run(3)
+    ora1 = po.selfplay(ocfg, 3, 21, 5, True)
+    parity.assert_same_games(rec1, ora1)
+    rec2 = eng.run(2)
+    ora2 = po.selfplay(ocfg, 2, 21, 5 + 3, True)
+    parity.assert_same_games(rec2, ora2)
+    st = eng.stats()
+    for k in ("games", "plies", "traversals", "expansions", "nodes_created"):
+        assert st[k] == ora1["stats"][k] + ora2["stats"][k], k
+    eng.close()
