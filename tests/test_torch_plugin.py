@@ -35,3 +35,41 @@ def test_rewritten_graph_matches_original(tmp_path):
         np.testing.assert_allclose(lo, rl.numpy(), atol=2e-5, rtol=0)
         np.testing.assert_allclose(va, rv.numpy().reshape(-1), atol=2e-5, rtol=0)
     plug.sprl_torch_free(h)
+
+
+def test_winograd_weight_transform_and_algebra_on_cpu():
+    """The host half of the hand-written trunk convolution, without a GPU: the plugin's weight transform (U = G g G^T,
+    stored in the kernel's A-operand lane order) fed through a numpy restatement of what the kernel computes
+    (V = B^T d B per 6x6 patch, 36 position-wise [64 x 64] products, Y = A^T M A) must equal the direct 3x3 convolution."""
+    plug = C.CDLL(os.path.join(os.path.dirname(E.DEFAULT_LIB), "libsprl_amd_torch.so"))
+    plug.sprl_wino_transform_weights.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((64, 64, 3, 3)) * 0.1).astype(np.float32)
+    x = rng.standard_normal((2, 64, 8, 8)).astype(np.float32)
+    u = np.zeros(36 * 64 * 64, np.float32)
+    plug.sprl_wino_transform_weights(w.ctypes.data, u.ctypes.data)
+    # undo the lane order: U4[p / 4][s][kb][lane][p % 4], lane = slot * 16 + k % 16, input channel = 16 (s >> 2) + 4 slot + (s & 3)
+    U = np.zeros((36, 64, 64), np.float64)                     # [p][k][c]
+    u4 = u.reshape(9, 16, 4, 64, 4)
+    for p in range(36):
+        for s in range(16):
+            for kb in range(4):
+                for lane in range(64):
+                    k = 16 * kb + lane % 16
+                    c = 16 * (s >> 2) + 4 * (lane // 16) + (s & 3)
+                    U[p, k, c] = u4[p // 4, s, kb, lane, p % 4]
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                   [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], np.float64)
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], np.float64)
+    xp = np.zeros((2, 64, 10, 10))
+    xp[:, :, 1:9, 1:9] = x
+    y = np.zeros((2, 64, 8, 8))
+    for n in range(2):
+        for ty in range(2):
+            for tx in range(2):
+                d = xp[n, :, 4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6]                  # [c][6][6]
+                V = np.einsum("ai,cij,bj->abc", BT, d, BT).reshape(36, 64)        # [p][c]
+                M = np.einsum("pkc,pc->pk", U, V).reshape(6, 6, 64)               # [xi][nu][k]
+                y[n, :, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4] = np.einsum("ia,abk,jb->kij", AT, M, AT)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), padding=1).numpy()
+    np.testing.assert_allclose(y, ref, atol=2e-5, rtol=0)     # fp32-rounded U against exact weights
