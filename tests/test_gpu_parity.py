@@ -319,3 +319,16 @@ def test_private_stream_cnn_games_equal_null_stream_games(lib, traced_model):
     (b1, p1), (s1, d1, o1) = recs[1]
     assert (b0 == b1).all() and (p0 == p1).all() and (o0 == o1).all()
     assert (d0.view(np.uint32) == d1.view(np.uint32)).all()
+
+
+def test_go9_with_traced_cnn_generic_path(lib, tmp_path):
+    """Boards wider than 8 have no hand-written trunk: the traced model runs through LibTorch (MIOpen convolutions or the
+    rewritten TorchScript graph).  Games must be complete and legal-looking, policies normalised."""
+    from sprl_amd.network import make_network, trace_to_file
+    model = trace_to_file(make_network("go9", 1, 32, seed=2), str(tmp_path / "traced_go9.pt"), "go9")
+    cfg, rec, st = parity.run_engine(lib, "go9", 6, model=model, concurrent_games=6, num_traversals=40)
+    states, dists, outcomes = rec.expand()
+    assert st["games"] == 6 and st["nn_evals"] > 0
+    assert states.shape[1:] == (17, 9, 9) and dists.shape[1] == 82
+    assert np.allclose(dists.sum(1), 1.0, atol=1e-4)
+    assert set(np.unique(outcomes).tolist()) <= {-1.0, 0.0, 1.0}
