@@ -68,6 +68,10 @@ typedef struct sprl_config {
     int32_t profile;           /* 1: time every tree-kernel launch with HIP events on its stream */
     int32_t own_stream;        /* 1: the engine works on a private non-blocking HIP stream instead of the null stream, so that
                                   several engines driven from different host threads overlap on one GPU */
+    float resign_threshold;    /* NOT in the reference (BASELINE config 5), 0 = off: after a search the side to move resigns
+                                  when the mean backed-up value of its decision node (sum W / sum N over its edges) is below
+                                  -resign_threshold; the ply's sample is kept, the opponent wins */
+    int32_t resign_min_ply;    /* no resignation before this ply */
     int32_t reserved_;
 } sprl_config;
 

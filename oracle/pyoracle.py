@@ -25,7 +25,7 @@ class Config(C.Structure):
         ("dir_eps", C.c_float), ("dir_alpha", C.c_float), ("u_weight", C.c_float),
         ("early_cutoff", C.c_int32), ("early_exp", C.c_float), ("rest_exp", C.c_float),
         ("use_sym", C.c_int32), ("add_noise", C.c_int32), ("eval_kind", C.c_int32), ("math_mode", C.c_int32),
-        ("mask_frame", C.c_int32), ("init_q", C.c_int32),
+        ("mask_frame", C.c_int32), ("init_q", C.c_int32), ("resign_threshold", C.c_float), ("resign_min_ply", C.c_int32),
         ("forward", FORWARD_FN), ("forward_user", C.c_void_p),
     ]
 
@@ -104,7 +104,8 @@ DEFAULTS = {
 
 def make_config(game, num_traversals, *, max_batch=None, max_queue=None, dir_eps=None, dir_alpha=None,
                 u_weight=1.1, early_cutoff=15, early_exp=0.98, rest_exp=10.0, use_sym=1, add_noise=1,
-                eval_kind=EVAL_RANDOM, math_mode=MATH_LIBM, mask_frame=MASK_REFERENCE, forward=None, init_q=0):
+                eval_kind=EVAL_RANDOM, math_mode=MATH_LIBM, mask_frame=MASK_REFERENCE, forward=None, init_q=0,
+                resign_threshold=0.0, resign_min_ply=0):
     d = DEFAULTS[game]
     cfg = Config()
     cfg.game = game
@@ -123,6 +124,8 @@ def make_config(game, num_traversals, *, max_batch=None, max_queue=None, dir_eps
     cfg.math_mode = math_mode
     cfg.mask_frame = mask_frame
     cfg.init_q = init_q
+    cfg.resign_threshold = resign_threshold
+    cfg.resign_min_ply = resign_min_ply
     if forward is not None:
         cfg.forward = forward
     return cfg

@@ -1058,7 +1058,7 @@ static int self_play(const orc_config* cfg, orc_rng* rng, orc_stats* st, int cap
     geom_t g = t.g;
     int A = g.A;
     int nsym = cfg->use_sym ? g.nsym : 1;
-    int n = n0, move_count = 0;
+    int n = n0, move_count = 0, resign_winner = -1;
     int movers[1024];
     (void)sizes;
     while (!t.decision->terminal) {
@@ -1096,6 +1096,21 @@ static int self_play(const orc_config* cfg, orc_rng* rng, orc_stats* st, int cap
             memset(out, 0, (size_t)A * sizeof(float));
             orc_symmetrize_dist(cfg->game, s, pdf, out);
         }
+        if (cfg->resign_threshold > 0.0f && move_count >= cfg->resign_min_ply) {
+            /* extension (BASELINE config 5), off in every parity configuration: mean backed-up value of the
+               decision node from the mover's side, sums in index order; the sample of this ply is kept, no move is made */
+            float sn = 0.0f, sw = 0.0f;
+            for (int a = 0; a < A; ++a) sn += t.decision->N[a];
+            for (int a = 0; a < A; ++a) sw += t.decision->W[a];
+            float v = sw * (1.0f / sn);
+            if (v < -cfg->resign_threshold) {
+                movers[move_count] = t.decision->player;
+                resign_winner = 1 - t.decision->player;
+                ++move_count;
+                n += nsym;
+                break;
+            }
+        }
         int action = orc_sample_cdf(rng, cdf, A);                            /* :140 */
         movers[move_count] = t.decision->player;
         advance_decision(&t, action);
@@ -1103,7 +1118,7 @@ static int self_play(const orc_config* cfg, orc_rng* rng, orc_stats* st, int cap
         n += nsym;
     }
     float rw[2];
-    rewards_of(t.decision->winner, rw);                                      /* :151-189 */
+    rewards_of(resign_winner >= 0 ? resign_winner : t.decision->winner, rw); /* :151-189 */
     for (int p = 0; p < move_count; ++p)
         for (int s = 0; s < nsym; ++s) outcomes[n0 + p * nsym + s] = rw[movers[p]];
     if (st) {

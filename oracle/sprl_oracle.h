@@ -55,6 +55,9 @@ typedef struct {
     int32_t math_mode;       /* ORC_MATH_* */
     int32_t mask_frame;      /* ORC_MASK_* (Q1; reference = original-frame mask on symmetrised policy) */
     int32_t init_q;          /* 0 = InitQ::PARENT (workers), 1 = InitQ::ZERO (UCTNode.hpp:24-28,267-273) */
+    float resign_threshold;  /* NOT in the reference, 0 = off: after a search, the side to move resigns when the mean
+                                backed-up value of its decision node, sum W / sum N over the edges, is below -threshold */
+    int32_t resign_min_ply;  /* no resignation before this ply */
     orc_forward_fn forward;  /* ORC_EVAL_CALLBACK */
     void* forward_user;
 } orc_config;

@@ -297,6 +297,7 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     if (cfg->stream_base < 1) return fail(SPRL_E_CONFIG, "stream_base must be >= 1 (stream 0 means 'pick one' in the reference)");
     if (cfg->node_cap < 0 || cfg->node_cap > 65535) return fail(SPRL_E_CONFIG, "node_cap must be <= 65535");
     if (!(cfg->dir_alpha > 0.0f)) return fail(SPRL_E_CONFIG, "dir_alpha must be > 0");
+    if (cfg->resign_threshold < 0.0f || cfg->resign_threshold >= 1.0f) return fail(SPRL_E_CONFIG, "resign_threshold must be in [0, 1)");
     std::string err;
     if (be::init(cfg->device, &err) != 0) return fail(SPRL_E_DEVICE, "no usable gfx950 device: " + err);
 
@@ -322,6 +323,8 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.early_cutoff = cfg->early_cutoff;
     P.early_exp = cfg->early_exp;
     P.rest_exp = cfg->rest_exp;
+    P.resign_threshold = cfg->resign_threshold;
+    P.resign_min_ply = cfg->resign_min_ply;
     P.use_sym = cfg->use_symmetry ? 1 : 0;
     P.add_noise = cfg->add_noise ? 1 : 0;
     P.eval_kind = EVAL_RANDOM;

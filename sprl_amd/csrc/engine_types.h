@@ -109,6 +109,8 @@ struct EngineParams {
     uint64_t seed;
     int32_t node_cap, num_slots, num_spare, num_games, max_plies, rounds;
     int32_t max_depth, planes;
+    float resign_threshold; // 0 = off (not in the reference): resign when sum W / sum N at the decision node < -threshold
+    int32_t resign_min_ply;
     int32_t init_q_zero;    // 0 = InitQ::PARENT (workers), 1 = InitQ::ZERO (uct/UCTNode.hpp:24-28,267-273)
     // match play (Evaluate.cpp): per-agent options, agent = slot & 1, game = slot >> 1
     int32_t m_use_sym[2], m_eval_kind[2], m_init_q_zero[2];

@@ -729,7 +729,7 @@ SPRL_DEV void advance_root(const EngineParams& P, Game& g, int slot, WaveLds<G>*
 
 // SelfPlay.hpp:110-148: visit pdf, temperature, CDF sample, record, re-root
 template <class G>
-SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds) {
+SPRL_DEV_NOINLINE int play_move(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds) {
     const int l = wv::lane();
     uint8_t* np = node_at(g.abase, g.root);
     const NodeHdr hcopy = load_hdr(np);
@@ -764,13 +764,29 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g, int slot, WaveL
     cdf = cdf * inv;
     last = last * inv;
     // record (compact): board, mover, tempered pdf
-    if (g.ply >= P.max_plies) { raise_error(P, g, ERR_MAX_PLIES); return; }
+    if (g.ply >= P.max_plies) { raise_error(P, g, ERR_MAX_PLIES); return 0; }
     const size_t rec = (size_t)g.game_id * (size_t)P.max_plies + (size_t)g.ply;
     P.rec_boards[rec * 2 + 0] = h->p0;
     P.rec_boards[rec * 2 + 1] = h->p1;
     P.rec_movers[rec] = h->player;
     if (l < G::NA) P.rec_pdf[rec * G::A + l] = pdf;
     if (G::HAS_PASS) P.rec_pdf[rec * G::A + (G::A - 1)] = pass_pdf;
+    if (P.resign_threshold > 0.0f && g.ply >= P.resign_min_ply) {
+        // extension, off in every parity configuration: the side to move resigns when the mean backed-up value of its
+        // decision node, sum W / sum N over the edges (index order, like the oracle), is below -threshold.  The ply's
+        // sample stays, no move is made; the caller ends the game for the opponent.
+        const float wrow = l < G::NA ? rowW(np)[l] : 0.0f;
+        float sn = 0.0f, sw = 0.0f;
+        for (uint64_t m = nz; m; m &= m - 1) sn += wv::bcast_f32(visits, wv::ctz64(m));
+        if (G::HAS_PASS) sn += pass_visits;
+        for (uint64_t m = nz; m; m &= m - 1) sw += wv::bcast_f32(wrow, wv::ctz64(m));
+        if (G::HAS_PASS) sw += h->passW;
+        const float v = sw * (1.0f / sn);
+        if (v < -P.resign_threshold) {
+            g.d_plies++;
+            return 2 - (int)h->player;              // winner + 1 = (1 - mover) + 1
+        }
+    }
     // Random::SampleCDF (utils/random.cpp:86-98)
     float e;
     do {
@@ -781,6 +797,7 @@ SPRL_DEV_NOINLINE void play_move(const EngineParams& P, Game& g, int slot, WaveL
     const int action = ge ? wv::ctz64(ge) : G::A - 1;
     advance_root<G>(P, g, slot, lds, action);
     g.d_plies++;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -881,12 +898,13 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
         // while (traversals < numTraversals) ... ; then the move; then the next ply's search begins
         bool idle = false;
         while (g.traversals >= P.num_traversals) {
-            { SPRL_TIC(t_m); play_move<G>(P, g, slot, lds); SPRL_TOC(g.cyc_move, t_m); }
+            int resigned;
+            { SPRL_TIC(t_m); resigned = play_move<G>(P, g, slot, lds); SPRL_TOC(g.cyc_move, t_m); }
             if (g.status != ST_ACTIVE) break;
             const NodeHdr rh = load_hdr(node_at(g.abase, g.root));
-            if (rh.flags & F_TERMINAL) {                          // SelfPlay.hpp:85,151
-                P.rec_nplies[g.game_id] = g.ply;
-                P.rec_winner[g.game_id] = rh.winner;
+            if (resigned || (rh.flags & F_TERMINAL)) {            // SelfPlay.hpp:85,151 (or the resign extension)
+                P.rec_nplies[g.game_id] = resigned ? g.ply + 1 : g.ply;
+                P.rec_winner[g.game_id] = resigned ? (int8_t)(resigned - 1) : rh.winner;
                 g.d_games++;
                 if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
                 start_game<G>(P, g, slot, lds);

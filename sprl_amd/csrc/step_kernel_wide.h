@@ -607,7 +607,7 @@ SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>*
 
 // SelfPlay.hpp:110-148
 template <class G>
-SPRL_DEV void play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds) {
+SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds) {
     const int l = wv::lane();
     uint8_t* np = node_at<G>(g.abase, g.root);
     const NodeHdrW<G::WORDS> h = load_hdr<G>(np);
@@ -649,7 +649,7 @@ SPRL_DEV void play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* 
     inv = 1.0f / last;
     for (int st = 0; st < WS; ++st) cdf[st] = cdf[st] * inv;
     last = last * inv;
-    if (g.ply >= P.max_plies) { raise_error(P, g, ERR_MAX_PLIES); return; }
+    if (g.ply >= P.max_plies) { raise_error(P, g, ERR_MAX_PLIES); return 0; }
     const size_t rec = (size_t)g.game_id * (size_t)P.max_plies + (size_t)g.ply;
     Bits<G::WORDS>* rb = (Bits<G::WORDS>*)P.rec_boards + rec * 2;
     rb[0] = h.p0;
@@ -658,6 +658,22 @@ SPRL_DEV void play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* 
     for (int st = 0; st < WS; ++st)
         if (st * 64 + l < G::NA) P.rec_pdf[rec * G::A + st * 64 + l] = pdf[st];
     P.rec_pdf[rec * G::A + (G::A - 1)] = pass_pdf;
+    if (P.resign_threshold > 0.0f && g.ply >= P.resign_min_ply) {     // extension (see step_kernel.h: play_move), default off
+        float sn = 0.0f, sw = 0.0f;
+        for (int st = 0; st < WS; ++st)
+            for (uint64_t m = nz[st]; m; m &= m - 1) sn += wv::bcast_f32(visits[st], wv::ctz64(m));
+        sn += pass_visits;
+        for (int st = 0; st < WS; ++st) {
+            const float wrow = st * 64 + l < G::NA ? rowW<G>(np)[st * 64 + l] : 0.0f;
+            for (uint64_t m = nz[st]; m; m &= m - 1) sw += wv::bcast_f32(wrow, wv::ctz64(m));
+        }
+        sw += h.passW;
+        const float v = sw * (1.0f / sn);
+        if (v < -P.resign_threshold) {
+            g.d_plies++;
+            return 2 - (int)h.player;
+        }
+    }
     float e;
     do {
         e = rng_uniform_float(g.rng);
@@ -708,6 +724,7 @@ SPRL_DEV void play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* 
     g.epoch += 1;
     g.traversals = 0;
     g.d_plies++;
+    return 0;
 }
 
 template <class G>
@@ -751,12 +768,12 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
         }
         bool idle = false;
         while (g.traversals >= P.num_traversals) {
-            play_move<G>(P, g, slot, lds);
+            const int resigned = play_move<G>(P, g, slot, lds);
             if (g.status != ST_ACTIVE) break;
             const NodeHdrW<G::WORDS> rh = load_hdr<G>(node_at<G>(g.abase, g.root));
-            if (rh.flags & F_TERMINAL) {
-                P.rec_nplies[g.game_id] = g.ply;
-                P.rec_winner[g.game_id] = rh.winner;
+            if (resigned || (rh.flags & F_TERMINAL)) {
+                P.rec_nplies[g.game_id] = resigned ? g.ply + 1 : g.ply;
+                P.rec_winner[g.game_id] = resigned ? (int8_t)(resigned - 1) : rh.winner;
                 g.d_games++;
                 if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
                 start_game<G>(P, g, slot, lds);

@@ -32,7 +32,8 @@ class Config(C.Structure):
         ("u_weight", C.c_float), ("early_cutoff", C.c_int32), ("early_exp", C.c_float), ("rest_exp", C.c_float),
         ("use_symmetry", C.c_int32), ("add_noise", C.c_int32), ("mask_frame", C.c_int32), ("node_cap", C.c_int32),
         ("spare_arenas", C.c_int32), ("max_plies", C.c_int32), ("seed", C.c_uint64), ("stream_base", C.c_int32),
-        ("profile", C.c_int32), ("own_stream", C.c_int32), ("reserved_", C.c_int32),
+        ("profile", C.c_int32), ("own_stream", C.c_int32), ("resign_threshold", C.c_float),
+        ("resign_min_ply", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

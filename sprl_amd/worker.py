@@ -111,7 +111,7 @@ def _write_npy_reference_header(f, arr):
 
 
 def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, concurrent_games=None, lib=None,
-               model_for_iteration=None, log=print, device=0):
+               model_for_iteration=None, log=print, device=0, resign_threshold=0.0, resign_min_ply=0):
     """The worker loop (GridWorker.hpp:111-197) for task ids [task_id, task_id + cover)."""
     lib = lib or E.load_library()
     num_iters = consts.num_iters if num_iters is None else num_iters
@@ -132,7 +132,8 @@ def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, co
         total = games * cover
         cfg = E.default_config(consts.game, lib, device=device, concurrent_games=min(concurrent_games or total, total),
                                num_traversals=trav, max_batch=mb, max_queue=mq, dir_eps=consts.dir_eps,
-                               dir_alpha=consts.dir_alpha, seed=seed, stream_base=next_stream)
+                               dir_alpha=consts.dir_alpha, seed=seed, stream_base=next_stream,
+                               resign_threshold=resign_threshold, resign_min_ply=resign_min_ply)
         next_stream += total
         eng = E.Engine(cfg, lib)
         log("Using initial network..." if model == "random" else "Using traced PyTorch network...")
@@ -158,6 +159,10 @@ def main(argv=None):
     ap.add_argument("--num-iters", type=int)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--seed", type=int)
+    ap.add_argument("--resign-threshold", type=float, default=0.0,
+                    help="extension, not in the reference (default off): the side to move resigns when the mean value of its "
+                         "decision node after the search is below -threshold")
+    ap.add_argument("--resign-min-ply", type=int, default=0)
     try:
         args = ap.parse_args(argv)
     except SystemExit:
@@ -170,7 +175,8 @@ def main(argv=None):
     if args.run_name:
         consts = WorkerConstants(**{**consts.__dict__, "run_name": args.run_name})
     print(f"Task {args.task_id} of {args.num_tasks}, covering {args.cover} task(s).")
-    run_worker(consts, args.task_id, cover=args.cover, num_iters=args.num_iters, device=args.device, seed=args.seed)
+    run_worker(consts, args.task_id, cover=args.cover, num_iters=args.num_iters, device=args.device, seed=args.seed,
+               resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
     return 0
 
 

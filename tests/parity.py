@@ -13,7 +13,8 @@ def oracle_config(game, cfg, kind, forward=None):
                           dir_eps=cfg.dir_eps, dir_alpha=cfg.dir_alpha, u_weight=cfg.u_weight,
                           early_cutoff=cfg.early_cutoff, early_exp=cfg.early_exp, rest_exp=cfg.rest_exp,
                           use_sym=cfg.use_symmetry, add_noise=cfg.add_noise, eval_kind=kind,
-                          math_mode=po.MATH_PORTABLE, mask_frame=cfg.mask_frame, forward=forward)
+                          math_mode=po.MATH_PORTABLE, mask_frame=cfg.mask_frame, forward=forward,
+                          resign_threshold=cfg.resign_threshold, resign_min_ply=cfg.resign_min_ply)
 
 
 def run_engine(lib, game, num_games, model="random", forward=None, **cfg_kw):

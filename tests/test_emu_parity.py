@@ -253,3 +253,16 @@ def test_second_run_on_one_engine_continues_streams_and_counters(emu):
     for k in ("games", "plies", "traversals", "expansions", "nodes_created"):
         assert st[k] == ora1["stats"][k] + ora2["stats"][k], k
     eng.close()
+
+
+# ---- resign option (not in the reference, default off): device == oracle, sample of the resign ply kept ----
+
+@pytest.mark.parametrize("game,kw", [("c4", dict(num_traversals=40)), ("othello", dict(num_traversals=32)),
+                                     ("go", dict(num_traversals=24, max_batch=4, max_queue=2)),
+                                     ("go9", dict(num_traversals=20, max_batch=4, max_queue=2))])
+def test_resign_threshold(emu, game, kw):
+    n = 6 if game in ("c4", "othello") else 2
+    plain, _ = parity.check_case(emu, game, n, concurrent_games=2, seed=31, **kw)
+    rec, st = parity.check_case(emu, game, n, concurrent_games=2, seed=31, resign_threshold=0.05, resign_min_ply=4, **kw)
+    assert rec.total_plies < plain.total_plies          # some game was cut short
+    assert (rec.ply_offset[1:] - rec.ply_offset[:-1] > 4).all()

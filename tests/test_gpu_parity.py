@@ -332,3 +332,12 @@ def test_go9_with_traced_cnn_generic_path(lib, tmp_path):
     assert states.shape[1:] == (17, 9, 9) and dists.shape[1] == 82
     assert np.allclose(dists.sum(1), 1.0, atol=1e-4)
     assert set(np.unique(outcomes).tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def test_resign_threshold_on_device(lib):
+    """The resign extension (default off; BASELINE config 5 names it): device == oracle, single-strip and wide kernels."""
+    parity.check_case(lib, "othello", 8, concurrent_games=8, num_traversals=64, seed=31, resign_threshold=0.05, resign_min_ply=4)
+    parity.check_case(lib, "go9", 4, concurrent_games=4, num_traversals=48, seed=31, resign_threshold=0.05, resign_min_ply=4)
+    rec, _ = parity.check_case(lib, "go19", 2, concurrent_games=2, num_traversals=24, seed=31, resign_threshold=0.02,
+                               resign_min_ply=6)
+    assert (rec.ply_offset[1:] - rec.ply_offset[:-1] < 722).all()
