@@ -336,9 +336,32 @@ extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const flo
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// any H*W: one element per lane (boards such as 9x9 or 19x19, where a float4 would straddle channels)
+template <bool RESIDUAL>
+__global__ void __launch_bounds__(256) bn_relu_scalar_kernel(float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int64_t n, int hw, int channels) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / hw) % channels);
+        float v = x[i] * scale[c] + shift[c];
+        if (RESIDUAL) v += res[i];
+        x[i] = v > 0.0f ? v : 0.0f;
+    }
+}
+
 extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float* scale, const float* shift,
                                     int64_t numel, int channels, int hw, void* stream) {
-    if (hw % 4 != 0 || numel % 4 != 0) return -1;
+    if (hw % 4 != 0 || numel % 4 != 0) {
+        int64_t blocks = (numel + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        if (residual)
+            hipLaunchKernelGGL(bn_relu_scalar_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, residual, scale,
+                               shift, numel, hw, channels);
+        else
+            hipLaunchKernelGGL(bn_relu_scalar_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                               (const float*)nullptr, scale, shift, numel, hw, channels);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const int64_t n_vec = numel / 4;
     int64_t blocks = (n_vec + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;          // grid-stride over 16 workgroups per CU

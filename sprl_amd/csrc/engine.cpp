@@ -432,7 +432,7 @@ int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len) {
     const char* what = e->eval_kind == SPRL_EVAL_RANDOM      ? "random (in-kernel)"
                        : e->eval_kind == SPRL_EVAL_HEURISTIC ? "heuristic (in-kernel)"
                        : e->forward_cb                      ? "forward callback"
-                       : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2)
+                       : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2 && e->g.rows <= 8 && e->g.cols <= 8)
                            ? "hand-written gfx950 CNN: MFMA stem + Winograd F(4x4,3x3) fp32-MFMA trunk with fused BN/residual/ReLU + fused heads/FC tail"
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model))
                            ? "LibTorch-ROCm: MIOpen convolutions + fused bias/BN/ReLU epilogue kernel"

@@ -321,6 +321,34 @@ def test_private_stream_cnn_games_equal_null_stream_games(lib, traced_model):
     assert (d0.view(np.uint32) == d1.view(np.uint32)).all()
 
 
+def test_go9_plugin_forward_matches_torchscript(lib, tmp_path):
+    """9x9 boards: library convolutions + the hand-written bias/BN/ReLU(/residual) epilogue and fused 1x1 heads (H*W = 81 is
+    not a multiple of 4: scalar epilogue form) against the plain TorchScript fp32 forward, 1e-4 absolute."""
+    import ctypes as C
+    import torch
+    from sprl_amd.network import make_network, trace_to_file
+    model = trace_to_file(make_network("go9", 2, 64, seed=4), str(tmp_path / "traced_go9b.pt"), "go9")
+    plug = C.CDLL(os.path.join(os.path.dirname(E.DEFAULT_LIB), "libsprl_amd_torch.so"))
+    plug.sprl_torch_load.restype = C.c_void_p
+    plug.sprl_torch_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    plug.sprl_torch_forward.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p,
+                                                                                 C.c_char_p, C.c_int]
+    err = C.create_string_buffer(512)
+    h = plug.sprl_torch_load(model.encode(), 0, err, 512)
+    assert h, err.value
+    ref = torch.jit.load(model, map_location="cuda").eval()
+    for batch in (5, 1024):
+        x = (torch.rand(batch, 17, 9, 9, device="cuda") > 0.6).float().contiguous()
+        lo = torch.zeros(batch, 82, device="cuda")
+        va = torch.zeros(batch, device="cuda")
+        assert plug.sprl_torch_forward(h, x.data_ptr(), batch, 17, 9, 9, lo.data_ptr(), 82, va.data_ptr(), err, 512) == 0, err.value
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            rl, rv = ref(x)
+        np.testing.assert_allclose(lo.cpu().numpy(), rl.cpu().numpy(), atol=1e-4, rtol=0)
+        np.testing.assert_allclose(va.cpu().numpy(), rv.cpu().numpy().reshape(-1), atol=1e-4, rtol=0)
+
+
 def test_go9_with_traced_cnn_generic_path(lib, tmp_path):
     """Boards wider than 8 have no hand-written trunk: the traced model runs through LibTorch (MIOpen convolutions or the
     rewritten TorchScript graph).  Games must be complete and legal-looking, policies normalised."""
