@@ -12,20 +12,19 @@
 //   tile = 2 ty + tx; 4096 floats per board, cells outside an H x W board hold zeros.
 // A channel quad of the K loop (one MFMA K step) is one group g: 1 KB contiguous per board.
 //
-// Workgroup = 8 waves (2 per SIMD) = 8 boards = 32 tiles, K loop over the 16 groups:
-//   * activations: two groups x 8 boards per chunk, zero-bordered 10x10 images in LDS (double buffered; strides chosen
-//     so that the 32 lanes of a bank group read 32 different banks);
-//   * B operand: for every chunk the 512 threads build V[2 groups][36][4 ch][32 tiles] ONCE into LDS (thread = one
-//     channel, one tile, three of the six transform rows: two 1-D transforms of its 6x6 patch, ~80 VALU operations),
-//     double buffered, in the lane order the MFMA wants, so a B fetch is one conflict-free ds_read;
-//   * A operand: weights pre-transformed on the host (U = G g G^T) and stored in lane order, so every A fetch is one
-//     coalesced 256-byte load from L2 (590 KB per layer, shared by every workgroup), used for both tile blocks;
-//   * wave (kb, half) accumulates output channels 16kb..16kb+15 for transform positions 18half..18half+17 and all
-//     32 tiles: 36 accumulator tiles of 16x16 (144 registers).  Producing V(s+1) (VALU + LDS) overlaps the MFMAs
-//     of V(s) inside a wave and across the two waves of a SIMD.
-// Output: the two waves of a kb swap halves through LDS (16-byte accesses), so that each lane then holds all 36
-// positions of its four (channel, tile) pairs: inverse transform in registers, scale/shift, residual, ReLU, and
-// 16-byte stores that are contiguous over 16 lanes (256-byte rows of layout W).
+// Common to both kernel versions below, K loop over the 16 groups, two groups (8 channels) per phase:
+//   * activations: a chunk of 8 channels per board group, zero-bordered 10x10 images in LDS (double buffered; strides
+//     chosen so that the 32 lanes of a bank group read 32 different banks);
+//   * B operand: for every chunk the threads build V[2 groups][36][4 ch][tiles] ONCE into LDS (thread = one channel, one
+//     tile, three of the six transform rows: two factored 1-D transforms of its 6x6 patch, ~80 VALU operations), double
+//     buffered, in the lane order the MFMA wants, so a B fetch is one conflict-free ds_read;
+//   * A operand: weights pre-transformed on the host (U = G g G^T) and stored in lane order, four transform positions per
+//     16-byte load (590 KB per layer, L2-resident), through a 36-register ring one group ahead of the MFMAs;
+//   * output: every lane ends the K loop with all 36 positions of its four (channel, tile) pairs: inverse transform in
+//     registers, scale/shift, residual, ReLU, 16-byte stores that are contiguous over 16 lanes (256-byte rows of layout W).
+// Version 2 (the product): 4 waves = 4 boards = 16 tiles per workgroup, two workgroups per CU.
+// Version 3 (SPRL_WINO_V3=1): 8 waves = 8 boards = 32 tiles, one workgroup per CU, weight fragments shared by two waves
+// through the vector cache.  Both measure the same in the whole network.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
