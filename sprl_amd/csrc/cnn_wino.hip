@@ -562,6 +562,176 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// General boards (any H x W, e.g. Go 9x9 and 19x19), plain NCHW activations in and out: same Winograd / MFMA core as
+// version 2, but a workgroup takes 16 consecutive TILES of the batch (boards are ceil(H/4) x ceil(W/4) tiles, a tile's
+// 6x6 input patch reaches into its neighbours), so the loader gathers the 36 patch values of every (channel, tile) straight
+// from global memory into LDS patches [slot][tile][37] (slot stride 592 = 16 mod 32: a 32-lane bank group reads 32 banks).
+// Used by the library-convolution path for its trunk convolutions (torch_eval.cpp) - the stem and the heads stay as they are.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PS_G = 37, SS_G = 16 * PS_G;            // patch stride, channel-slot stride
+constexpr int IN_BUF_G = 8 * SS_G;
+constexpr int LDS_FLOATS_G = 2 * IN_BUF_G + 4 * V_G2;  // 74.8 KB: two workgroups per CU
+constexpr int NLD_G = (8 * 16 * 36) / NTHR2;          // 18 patch values per thread and chunk
+
+__global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    const float* __restrict__ res, float* __restrict__ y, int batch,
+                                                                    int H, int W, int relu) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS_G];
+    float* const in_buf = lds;
+    float* const v_buf = lds + 2 * IN_BUF_G;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c_sub = lane >> 4, tl = lane & 15;
+    const int gl = wave & 1, wa = wave >> 1;
+    const int kb = wave;
+    const int TX = (W + 3) >> 2, TY = (H + 3) >> 2, TPB = TX * TY;
+    const int HW = H * W;
+    // this thread's tile (the same one as loader, tid & 15, and as MFMA column / output lane, lane & 15)
+    const int total_tiles = batch * TPB;              // the host keeps batch * tiles-per-board below 2^31
+    const int tg = (int)blockIdx.x * 16 + tl;
+    const int t_n = tg < total_tiles ? tg / TPB : -1;
+    const int t_tt = tg < total_tiles ? tg % TPB : 0;
+    const int t_row0 = 4 * (t_tt / TX), t_col0 = 4 * (t_tt % TX);
+
+    f4 acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    // chunk = groups 2c, 2c+1: 8 channel slots x 16 tiles x 36 patch values.  Loader thread = (tile, slot, half): the
+    // three patch rows 3 half .. 3 half + 2 of one (channel slot, tile), 18 values
+    const int ld_tile = tl, ld_slot = (tid >> 4) & 7, ld_half = tid >> 7;
+    const int ld_n = t_n;
+    const int ld_row = t_row0 - 1 + 3 * ld_half, ld_col = t_col0 - 1;
+    const int ld_lds = ld_slot * SS_G + ld_tile * PS_G + 18 * ld_half;
+    bool colok[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) colok[j] = ld_n >= 0 && ld_col + j >= 0 && ld_col + j < W;
+    float pre[NLD_G];
+    auto gload = [&](int chunk) {
+        const int g = 2 * chunk + (ld_slot >> 2);
+        const int k = 16 * (g >> 2) + 4 * (ld_slot & 3) + (g & 3);
+        const float* src = x + ((size_t)(ld_n < 0 ? 0 : ld_n) * 64 + (size_t)k) * HW + ld_col;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int row = ld_row + i;
+            const bool rowok = row >= 0 && row < H;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) pre[i * 6 + j] = (rowok && colok[j]) ? src[row * W + j] : 0.0f;
+        }
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int q = 0; q < NLD_G; ++q) buf[ld_lds + q] = pre[q];
+    };
+    const int patch0 = (gl * 4 + c_sub) * SS_G + tl * PS_G + wa * 6;
+    const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
+    auto produce = [&](int c) {
+        const float* pp = in_buf + (c & 1) * IN_BUF_G + patch0;
+        float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
+        float wr[3][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
+            const float st = 4.0f * e0 - 5.0f * e2 + e4;
+            if (wa == 0) {
+                const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                wr[0][j] = st;
+                wr[1][j] = p + q;
+                wr[2][j] = p - q;
+            } else {
+                const float p = e3 - e1, q = 2.0f * (e2 - e0);
+                wr[0][j] = p + q;
+                wr[1][j] = p - q;
+                wr[2][j] = st;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+            const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
+            vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
+            vd[(r * 6 + 1) * 64] = p + q;
+            vd[(r * 6 + 2) * 64] = p - q;
+            vd[(r * 6 + 3) * 64] = p2 + q2;
+            vd[(r * 6 + 4) * 64] = p2 - q2;
+            vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
+        }
+    };
+    const f4* ua = (const f4*)u + kb * 64 + lane;
+    f4 a[9];
+    auto aload = [&](int s, int k) { a[k] = ua[(size_t)k * (16 * 4 * 64) + s * 256]; };
+    auto mma = [&](const float* vg, int k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float b = vg[(k * 4 + q) * 64 + lane];
+            acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
+        }
+    };
+    auto phase = [&](int c) {
+        const float* vs = v_buf + (c & 1) * 2 * V_G2;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int s = 2 * c + g2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                mma(vs + g2 * V_G2, k);
+                if (s + 1 < 16) aload(s + 1, k);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < 8) produce(c + 1);
+        if (c + 2 < 8) {
+            lstore(in_buf + (c & 1) * IN_BUF_G);
+            if (c + 3 < 8) gload(c + 3);
+        }
+        __syncthreads();
+    };
+
+    gload(0);
+    lstore(in_buf);
+    gload(1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aload(0, k);
+    lstore(in_buf + IN_BUF_G);
+    gload(2);
+    __syncthreads();
+    produce(0);
+    __syncthreads();
+    for (int c = 0; c < 8; ++c) phase(c);
+
+    // ---- inverse transform in registers + epilogue, NCHW ----
+    const int n = t_n, row0 = t_row0, col0 = t_col0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        float m[6][6];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = acc[p][r];
+        float o[4][4];
+        inverse_transform(m, o);
+        const int k = 16 * kb + 4 * c_sub + r;
+        const float sc = scale[k], sh = shift[k];
+        if (n >= 0) {
+            const size_t plane = ((size_t)n * 64 + (size_t)k) * HW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = row0 + i, col = col0 + j;
+                    if (row < H && col < W) {
+                        const size_t at = plane + (size_t)row * W + col;
+                        float v = o[i][j] * sc + sh;
+                        if (res) v += res[at];
+                        if (relu) v = v > 0.0f ? v : 0.0f;
+                        y[at] = v;
+                    }
+                }
+        }
+    }
+}
+
 }  // namespace
 
 // sprl_wino_weight_layout(): 2 = U4[p / 4][s][kb][lane][p % 4] (what wino_transform must produce; 1 was U2[p][s][kb][lane])
@@ -638,5 +808,17 @@ extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const floa
     else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<6, 7, 0, 2>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
     else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_v2_kernel<7, 7, 0, 2>), grid, block, 0, st, x, u, scale, shift, res, nullptr, batch, 1, stagger, batch_dev, ta);
     else return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Any board size, NCHW activations [batch][64][H][W] in and out (res may be null; y must not alias x); same weights `u`.
+extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                     float* y, int batch, int H, int W, int relu, void* stream) {
+    if (batch <= 0) return 0;
+    if (H < 1 || W < 1 || H > 64 || W > 64) return -1;
+    const long long tiles = (long long)batch * ((H + 3) / 4) * ((W + 3) / 4);
+    if (tiles > 0x7fffffffLL - 16) return -1;
+    const dim3 grid((unsigned)((tiles + 15) / 16)), block(NTHR2);
+    hipLaunchKernelGGL(wino_conv64_nchw_kernel, grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

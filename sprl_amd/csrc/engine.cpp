@@ -434,6 +434,8 @@ int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len) {
                        : e->forward_cb                      ? "forward callback"
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2 && e->g.rows <= 8 && e->g.cols <= 8)
                            ? "hand-written gfx950 CNN: MFMA stem + Winograd F(4x4,3x3) fp32-MFMA trunk with fused BN/residual/ReLU + fused heads/FC tail"
+                       : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2)
+                           ? "library stem convolution + hand-written Winograd F(4x4,3x3) fp32-MFMA trunk (any board size) + fused heads kernel"
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model))
                            ? "LibTorch-ROCm: MIOpen convolutions + fused bias/BN/ReLU epilogue kernel"
                            : "LibTorch-ROCm: TorchScript graph (bias hoisted for the JIT fuser)";

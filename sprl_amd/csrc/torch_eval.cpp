@@ -23,6 +23,8 @@ extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float
 extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                     float* y, int batch, int H, int W, int relu, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_wino_weight_layout(void);
+extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                     float* y, int batch, int H, int W, int relu, void* stream);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_wino_conv64_tail(const float* x, const float* u, const float* scale, const float* shift, const float* res,
@@ -275,7 +277,25 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
     } else {
         at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
         if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
+        // boards wider than 8: the trunk still runs on the hand-written Winograd/MFMA kernel (any-board variant, NCHW);
+        // the stem (P planes) and the heads keep the library convolution / the NCHW heads kernel
+        const bool trunk_wino = n.wino && H0 <= 64 && W0 <= 64 && !getenv("SPRL_TORCH_NO_WINOGRAD_NCHW");
+        at::Tensor ya, za;
+        if (trunk_wino) {
+            ya = at::empty_like(x);
+            za = at::empty_like(x);
+        }
         for (const auto& b : n.blocks) {
+            if (trunk_wino) {
+                const int B0 = (int)x.size(0);
+                if (sprl_wino_conv64_nchw(x.data_ptr<float>(), b.u1.data_ptr<float>(), b.s1.data_ptr<float>(), b.t1.data_ptr<float>(),
+                                          nullptr, ya.data_ptr<float>(), B0, H0, W0, 1, nullptr) != 0 ||
+                    sprl_wino_conv64_nchw(ya.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(), b.t2.data_ptr<float>(),
+                                          x.data_ptr<float>(), za.data_ptr<float>(), B0, H0, W0, 1, nullptr) != 0)
+                    return false;
+                std::swap(x, za);
+                continue;
+            }
             at::Tensor y = at::conv2d(x, b.w1, {}, 1, 1);
             if (!y.is_contiguous() || !epilogue(y, b.s1, b.t1, nullptr)) return false;
             at::Tensor z = at::conv2d(y, b.w2, {}, 1, 1);

@@ -18,6 +18,7 @@ def plug():
     p = C.CDLL(os.path.join(os.path.dirname(E.DEFAULT_LIB), "libsprl_amd_torch.so"))
     p.sprl_wino_conv64.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
     p.sprl_wino_transform_weights.argtypes = [C.c_void_p, C.c_void_p]
+    p.sprl_wino_conv64_nchw.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
     return p
 
 
@@ -91,3 +92,31 @@ def test_wino_structured_inputs(plug):
     got = run_conv(plug, x, w, one, zero, None, False)
     want = torch.nn.functional.conv2d(x, w, padding=1)
     assert (got - want).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("H,W,B", [(9, 9, 7), (19, 19, 3), (8, 8, 5), (5, 7, 9), (9, 9, 300), (19, 19, 40), (13, 6, 11)])
+def test_wino_conv_general_boards_nchw(plug, H, W, B):
+    """The any-board variant (workgroup = 16 tiles, patches gathered from NCHW) against conv2d in float64."""
+    import torch
+    torch.manual_seed(H * 1000 + W * 10 + B)
+    x = torch.randn(B, 64, H, W, device="cuda")
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.06
+    scale = torch.rand(64, device="cuda") + 0.5
+    shift = torch.randn(64, device="cuda") * 0.3
+    res = torch.randn(B, 64, H, W, device="cuda")
+    u = np.zeros(36 * 64 * 64, np.float32)
+    wc = np.ascontiguousarray(w.cpu().numpy())          # keep the host copy alive across the call
+    plug.sprl_wino_transform_weights(wc.ctypes.data, u.ctypes.data)
+    ud = torch.from_numpy(u).cuda()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    for use_res, relu in ((True, True), (False, False)):
+        want = ref + res.double() if use_res else ref
+        if relu:
+            want = torch.relu(want)
+        y = torch.full_like(x, float("nan"))
+        rc = plug.sprl_wino_conv64_nchw(x.data_ptr(), ud.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                        res.data_ptr() if use_res else None, y.data_ptr(), B, H, W, int(relu), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        err = (y.double() - want).abs().max().item()
+        assert err < 2e-4, (H, W, B, use_res, relu, err)

@@ -47,7 +47,8 @@ def main():
         w = torch.randn(64, 64, 3, 3, device="cuda") * 0.06
         sc, sh = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda")
         u = np.zeros(36 * 64 * 64, np.float32)
-        plug.sprl_wino_transform_weights(np.ascontiguousarray(w.cpu().numpy()).ctypes.data, u.ctypes.data)
+        wc = np.ascontiguousarray(w.cpu().numpy())
+        plug.sprl_wino_transform_weights(wc.ctypes.data, u.ctypes.data)
         ud = torch.from_numpy(u).cuda()
         y = torch.empty_like(x)
         t_w = timeit(lambda: plug.sprl_wino_conv64(x.data_ptr(), ud.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(),
