@@ -13,9 +13,12 @@ from sprl_amd import engine as E  # noqa: E402
 from sprl_amd.network import make_network, trace_to_file  # noqa: E402
 
 
+LIB = [None]
+
+
 def measure(game, games, model, rounds, warm):
-    cfg = E.default_config(game, concurrent_games=games, num_traversals=1600, seed=3)
-    eng = E.Engine(cfg)
+    cfg = E.default_config(game, LIB[0], concurrent_games=games, num_traversals=1600, seed=3)
+    eng = E.Engine(cfg, LIB[0])
     eng.set_model(model)
     eng.begin(games)
     eng.step(warm)
@@ -35,13 +38,20 @@ def main():
     ap.add_argument("--games9", type=int, default=1024)
     ap.add_argument("--games19", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=400)
+    ap.add_argument("--warm", type=int, default=20, help="rounds played before the timed ones (100 rounds = one move)")
+    ap.add_argument("--no-cnn", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative libsprl_amd.so (A/B measurements)")
     ap.add_argument("--blocks", type=int, default=6)          # go_controller.py: MODEL_NUM_BLOCKS = 6
     a = ap.parse_args()
+    if a.lib:
+        LIB[0] = E.load_library(a.lib)
     with tempfile.TemporaryDirectory() as td:
         for game, games in (("go9", a.games9), ("go19", a.games19)):
             cnn = trace_to_file(make_network(game, a.blocks, 64, seed=0), os.path.join(td, f"{game}.pt"), game)
             for name, model, rounds in (("uniform evaluator (in kernel)", "random", a.rounds), ("traced CNN", cnn, a.rounds // 4)):
-                dt, d, info = measure(game, games, model, rounds, 20)
+                if a.no_cnn and model != "random":
+                    continue
+                dt, d, info = measure(game, games, model, rounds, a.warm)
                 print(f"{game}: {games} games, {name} [{info}]: {rounds} rounds in {dt:.2f} s -> "
                       f"{d['traversals'] / dt / 1e6:.2f} M traversals/s, {d['expansions'] / dt / 1e6:.2f} M expansions/s, "
                       f"{d['traversals'] / dt / 1600:.0f} moves/s, {d['nn_evals'] / dt / 1e6:.2f} M evals/s", flush=True)
