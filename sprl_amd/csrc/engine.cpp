@@ -323,6 +323,8 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.early_cutoff = cfg->early_cutoff;
     P.early_exp = cfg->early_exp;
     P.rest_exp = cfg->rest_exp;
+    if (const char* f = getenv("SPRL_GO_LEGAL"))           // test hook: both algorithms are checked on every board size
+        P.go_legal_form = strcmp(f, "label") == 0 ? 1 : (strcmp(f, "flood") == 0 ? 2 : 0);
     P.resign_threshold = cfg->resign_threshold;
     P.resign_min_ply = cfg->resign_min_ply;
     P.use_sym = cfg->use_symmetry ? 1 : 0;

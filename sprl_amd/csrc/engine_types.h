@@ -111,6 +111,7 @@ struct EngineParams {
     int32_t max_depth, planes;
     float resign_threshold; // 0 = off (not in the reference): resign when sum W / sum N at the decision node < -threshold
     int32_t resign_min_ply;
+    int32_t go_legal_form;  // wide Go kernel, legal-move computation: 0 by board size, 1 group labels, 2 per-lane flood fill
     int32_t init_q_zero;    // 0 = InitQ::PARENT (workers), 1 = InitQ::ZERO (uct/UCTNode.hpp:24-28,267-273)
     // match play (Evaluate.cpp): per-agent options, agent = slot & 1, game = slot >> 1
     int32_t m_use_sym[2], m_eval_kind[2], m_init_q_zero[2];

@@ -41,6 +41,7 @@ struct WaveLdsW {
     uint32_t leaf_size[SPRL_MAXQ];
     float xf[G::STRIPS * 64];                 // cross-strip exchange: one float / u32 / group mask per point
     uint32_t xu[G::STRIPS * 64];
+    uint32_t xl[G::STRIPS * 64];              // liberties per group label
     Bits<G::WORDS> xg[G::STRIPS * 64];
 };
 
@@ -60,6 +61,7 @@ struct GameW {
     uint32_t arena, root, n_alloc, epoch, root_player, game_id, status;
     float rootN, rootW;
     int ply, traversals, n_leaves;
+    int legal_form;         // EngineParams::go_legal_form
     uint32_t d_traversals, d_levels, d_expansions, d_nn_evals, d_terminal, d_gray, d_dup, d_created, d_compactions,
         d_games, d_plies;
 };
@@ -115,8 +117,9 @@ SPRL_DEV PosW<G::WORDS> pos_of(const NodeHdrW<G::WORDS>& h) {
 
 // Legal mask of a Go position (GoNode.cpp:178-228,292-301), point a = strip * 64 + lane: per-point group flood fill,
 // liberties, neighbour inspection through the LDS exchange, exact positional-superko compare with the ancestors.
+// Small boards (up to two strips): every stone lane flood-fills its own group as a bit set - fewer, wider steps.
 template <class G>
-SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, int n_hist) {
+SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, int n_hist) {
     using BB = Bits<G::WORDS>;
     const int l = wv::lane();
     const BB own = c.player ? c.p1 : c.p0, opp = c.player ? c.p0 : c.p1;
@@ -173,6 +176,114 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds,
     return legal;
 }
 
+// Large boards: per-lane bit sets would need 2 x STRIPS x WORDS registers and one wide dilate per step; groups are
+// labelled instead (measured at 19x19: 3.6-4.9x faster than the flood form; at 9x9 the flood form is 25 % faster).
+template <class G>
+SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, int n_hist, int form) {
+    // form: 0 = by board size (flood up to two strips, labels above), 1 = labels, 2 = flood (tests run both on every size)
+    if (form == 2 || (form == 0 && G::STRIPS <= 2)) return go_legal_mask_flood<G>(c, lds, n_hist);
+    using BB = Bits<G::WORDS>;
+    const int l = wv::lane();
+    const BB own = c.player ? c.p1 : c.p0, opp = c.player ? c.p0 : c.p1;
+    const BB board = G::board_mask();
+    const BB empty = ~(own | opp) & board;
+    // 1. connected groups: every stone takes the smallest point index of its group as label (min over same-coloured
+    //    neighbours + pointer jumping, until no label moves); one u32 per point in LDS, no per-lane bit sets
+    uint32_t lab[WS];
+    uint8_t colr[WS];                                    // 0 empty / off board, 1 own, 2 opponent
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        const bool on = a < G::CELLS;
+        colr[st] = (uint8_t)(on && own.test(a) ? 1 : (on && opp.test(a) ? 2 : 0));
+        lab[st] = colr[st] ? (uint32_t)a : 0xFFFFu;
+        lds->xl[st * 64 + l] = 0;
+    }
+    for (;;) {
+        for (int st = 0; st < WS; ++st) lds->xu[st * 64 + l] = lab[st];
+        wv::sync();
+        bool changed = false;
+        for (int st = 0; st < WS; ++st) {
+            if (!colr[st]) continue;
+            const int a = st * 64 + l, row = a / G::COLS, col = a % G::COLS;
+            const BB& mine = colr[st] == 1 ? own : opp;
+            uint32_t m = lab[st];
+            if (row > 0 && mine.test(a - G::COLS)) { const uint32_t v = lds->xu[a - G::COLS]; m = v < m ? v : m; }
+            if (col > 0 && mine.test(a - 1)) { const uint32_t v = lds->xu[a - 1]; m = v < m ? v : m; }
+            if (row < G::ROWS - 1 && mine.test(a + G::COLS)) { const uint32_t v = lds->xu[a + G::COLS]; m = v < m ? v : m; }
+            if (col < G::COLS - 1 && mine.test(a + 1)) { const uint32_t v = lds->xu[a + 1]; m = v < m ? v : m; }
+            const uint32_t j = lds->xu[m];               // the label's own label: halves the remaining distance
+            m = j < m ? j : m;
+            changed |= m != lab[st];
+            lab[st] = m;
+        }
+        wv::sync();
+        if (wv::ballot(changed) == 0) break;
+    }
+    // 2. liberties of a group = empty points touching it, each counted once
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        if (a < G::CELLS && empty.test(a)) {
+            const int row = a / G::COLS, col = a % G::COLS;
+            uint32_t seen[4];
+            int ns = 0;
+            for (int d = 0; d < 4; ++d) {
+                const bool valid = d == 0 ? row > 0 : d == 1 ? col > 0 : d == 2 ? row < G::ROWS - 1 : col < G::COLS - 1;
+                if (!valid) continue;
+                const int nb = d == 0 ? a - G::COLS : d == 1 ? a - 1 : d == 2 ? a + G::COLS : a + 1;
+                if (empty.test(nb)) continue;
+                const uint32_t g = lds->xu[nb];
+                bool dup = false;
+                for (int k = 0; k < ns; ++k) dup |= seen[k] == g;
+                if (!dup) {
+                    seen[ns++] = g;
+                    wv::atomic_add_u32(&lds->xl[g], 1u);
+                }
+            }
+        }
+    }
+    wv::sync();
+    // 3. stone masks of the opponent groups in atari (the only ones a move can capture), one wave-wide ballot pass each
+    for (int st = 0; st < WS; ++st) {
+        uint64_t reps = wv::ballot(colr[st] == 2 && lab[st] == (uint32_t)(st * 64 + l) && lds->xl[st * 64 + l] == 1u);
+        for (; reps; reps &= reps - 1) {
+            const uint32_t rep = (uint32_t)(st * 64 + wv::ctz64(reps));
+            BB gmask;
+            for (int s2 = 0; s2 < WS; ++s2) gmask.w[s2] = wv::ballot(colr[s2] == 2 && lab[s2] == rep);
+            if (l == 0) lds->xg[rep] = gmask;
+        }
+    }
+    wv::sync();
+    BB legal = BB::zero();
+    for (int st = 0; st < WS; ++st) {
+        const int a = st * 64 + l;
+        bool ok = false;
+        if (a < G::CELLS && empty.test(a)) {
+            const int row = a / G::COLS, col = a % G::COLS;
+            bool has_libs = false;
+            BB cap = BB::zero();
+            for (int d = 0; d < 4; ++d) {
+                const bool valid = d == 0 ? row > 0 : d == 1 ? col > 0 : d == 2 ? row < G::ROWS - 1 : col < G::COLS - 1;
+                if (!valid) continue;
+                const int nb = d == 0 ? a - G::COLS : d == 1 ? a - 1 : d == 2 ? a + G::COLS : a + 1;
+                if (empty.test(nb)) has_libs = true;
+                else {
+                    const uint32_t g = lds->xu[nb], libs = lds->xl[g];
+                    if (own.test(nb)) { if (libs > 1) has_libs = true; }
+                    else if (libs == 1) { has_libs = true; cap = cap | lds->xg[g]; }
+                }
+            }
+            const BB nown = own | BB::bit(a), nopp = opp & ~cap;
+            const BB np0 = c.player ? nopp : nown, np1 = c.player ? nown : nopp;
+            bool repeat = false;
+            for (int i = 0; i < n_hist; ++i) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
+            ok = has_libs && !repeat;
+        }
+        const uint64_t m = wv::ballot(ok);
+        legal.w[st] = m;
+    }
+    return legal;
+}
+
 template <class G>
 SPRL_DEV void make_child(GameW& g, WaveLdsW<G>* lds, const PosW<G::WORDS>& parent, int action, int at,
                          PosW<G::WORDS>& cs) {
@@ -182,7 +293,7 @@ SPRL_DEV void make_child(GameW& g, WaveLdsW<G>* lds, const PosW<G::WORDS>& paren
         lds->hist[at][1] = cs.p1;
     }
     wv::sync();
-    if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, at + 1);
+    if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, at + 1, g.legal_form);
 }
 
 // Dirichlet root noise (UCTNode.hpp:330-347, utils/random.cpp:61-74)
@@ -748,6 +859,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
     g.root_player = ctl->root_player;
     g.d_traversals = g.d_levels = g.d_expansions = g.d_nn_evals = g.d_terminal = g.d_gray = g.d_dup = 0;
     g.d_created = g.d_compactions = g.d_games = g.d_plies = 0;
+    g.legal_form = P.go_legal_form;
     g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * G::NODE_BYTES;
     wv::sync();
     if (g.status == ST_ACTIVE) {

@@ -266,3 +266,13 @@ def test_resign_threshold(emu, game, kw):
     rec, st = parity.check_case(emu, game, n, concurrent_games=2, seed=31, resign_threshold=0.05, resign_min_ply=4, **kw)
     assert rec.total_plies < plain.total_plies          # some game was cut short
     assert (rec.ply_offset[1:] - rec.ply_offset[:-1] > 4).all()
+
+
+@pytest.mark.parametrize("form", ["label", "flood"])
+def test_wide_go_legal_move_algorithms_agree_with_oracle(emu, form, monkeypatch):
+    """The wide kernel has two exact legal-move computations (group labels / per-lane flood fill) chosen by board size;
+    the SPRL_GO_LEGAL hook forces one of them so that each is checked against the oracle on 7x7 and 9x9 whole games
+    (19x19 runs the label form by default: test_go19_six_strip_rows)."""
+    monkeypatch.setenv("SPRL_GO_LEGAL", form)
+    parity.check_case(emu, "go7_wide", 2, concurrent_games=2, num_traversals=24, max_batch=4, max_queue=2, seed=9)
+    parity.check_case(emu, "go9", 1, concurrent_games=1, num_traversals=20, max_batch=4, max_queue=2, seed=9)
