@@ -332,22 +332,24 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
         const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
         ldst[it] = (g2 * 4 + cs) * CS2 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
     }
-    auto gload = [&](int chunk) {
+    auto gload_to = [&](int chunk, f4 (&dst)[2]) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int f = tid + NTHR2 * it;
             const int n = n0 + (f >> 7);
-            pre[it] = (ABL & 16) ? (f4){ 1.0f, 1.0f, 1.0f, 1.0f }
+            dst[it] = (ABL & 16) ? (f4){ 1.0f, 1.0f, 1.0f, 1.0f }
                       : n < batch ? __builtin_nontemporal_load((const f4*)(x + (size_t)n * 4096 + (size_t)chunk * 512 + (size_t)(f & 127) * 4))
                                   : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
         }
     };
-    auto lstore = [&](float* buf) {
+    auto lstore_from = [&](float* buf, const f4 (&src)[2]) {
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = pre[it][j];
+            for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = src[it][j];
     };
+    auto gload = [&](int chunk) { gload_to(chunk, pre); };
+    auto lstore = [&](float* buf) { lstore_from(buf, pre); };
     const int patch0 = (gl * 4 + c_sub) * CS2 + board_off(tl >> 2) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
     const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
     auto produce = [&](int c) {
@@ -429,13 +431,16 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
                                             : (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
     };
 
-    gload(0);
-    __syncthreads();                                   // zero fill done
-    lstore(in_buf);
-    gload(1);
+    {   // the first two chunks are requested together: one HBM round trip before the first V can be built, not two
+        f4 first[2];
+        gload_to(0, first);
+        gload(1);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) aload(0, k);
-    lstore(in_buf + IN_BUF2);
+        for (int k = 0; k < 9; ++k) aload(0, k);
+        __syncthreads();                               // zero fill done
+        lstore_from(in_buf, first);
+        lstore(in_buf + IN_BUF2);
+    }
     gload(2);
     __syncthreads();
     produce(0);
