@@ -708,9 +708,23 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
 
     // ---- inverse transform in registers + epilogue, NCHW ----
     const int n = t_n, row0 = t_row0, col0 = t_col0;
+    // residual values of output component r (channel 16 kb + 4 c_sub + r), requested one component ahead of their use
+    float rres[2][16];
+    auto rload = [&](int r, float (&dst)[16]) {
+        const size_t plane = ((size_t)(n < 0 ? 0 : n) * 64 + (size_t)(16 * kb + 4 * c_sub + r)) * HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + i, col = col0 + j;
+                dst[i * 4 + j] = (res && n >= 0 && row < H && col < W) ? res[plane + (size_t)row * W + col] : 0.0f;
+            }
+    };
+    rload(0, rres[0]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         __builtin_amdgcn_sched_barrier(0);
+        if (r + 1 < 4) rload(r + 1, rres[(r + 1) & 1]);
         float m[6][6];
 #pragma unroll
         for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = acc[p][r];
@@ -726,11 +740,9 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
                 for (int j = 0; j < 4; ++j) {
                     const int row = row0 + i, col = col0 + j;
                     if (row < H && col < W) {
-                        const size_t at = plane + (size_t)row * W + col;
-                        float v = o[i][j] * sc + sh;
-                        if (res) v += res[at];
+                        float v = o[i][j] * sc + sh + rres[r & 1][i * 4 + j];
                         if (relu) v = v > 0.0f ? v : 0.0f;
-                        y[at] = v;
+                        y[plane + (size_t)row * W + col] = v;
                     }
                 }
         }

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=400)
     ap.add_argument("--warm", type=int, default=20, help="rounds played before the timed ones (100 rounds = one move)")
     ap.add_argument("--no-cnn", action="store_true")
+    ap.add_argument("--only", default=None, choices=["go9", "go19"])
     ap.add_argument("--lib", default=None, help="alternative libsprl_amd.so (A/B measurements)")
     ap.add_argument("--blocks", type=int, default=6)          # go_controller.py: MODEL_NUM_BLOCKS = 6
     a = ap.parse_args()
@@ -47,6 +48,8 @@ def main():
         LIB[0] = E.load_library(a.lib)
     with tempfile.TemporaryDirectory() as td:
         for game, games in (("go9", a.games9), ("go19", a.games19)):
+            if a.only and game != a.only:
+                continue
             cnn = trace_to_file(make_network(game, a.blocks, 64, seed=0), os.path.join(td, f"{game}.pt"), game)
             for name, model, rounds in (("uniform evaluator (in kernel)", "random", a.rounds), ("traced CNN", cnn, a.rounds // 4)):
                 if a.no_cnn and model != "random":
