@@ -35,6 +35,7 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int NIMG = 8;                  // boards per workgroup
 constexpr int NTHR = 512;
@@ -565,6 +566,340 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v2_kernel(const float* _
         for (int msk = 32; msk >= 1; msk >>= 1) hsum += __shfl_xor(hsum, msk, 64);
         if (lane == 0 && nb < batch) ta.value[nb] = tanhf(hsum + ta.vfc2_b[0]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Version 4: version 2's structure (4 waves = 4 boards = 16 tiles per workgroup, two workgroups per CU, wave kb owns output
+// channels 16kb..16kb+15 for all 36 transform positions), but the A operand is no longer streamed from L2 in the Winograd
+// domain.  Version 2 is bound by that stream: 36 x 64 x 64 floats = 590 KB per workgroup of 4 boards, about 28 B/clk per CU
+// with two resident workgroups - the rate an L2-served stream into one CU reaches.  Version 4 streams the 3x3 filters
+// themselves (9 floats per (out, in) pair: a quarter of the bytes) and builds U = G g G^T in registers in front of the MFMAs
+// that use it: per K step and lane 33 + 66 vector operations (rows of T = G g just in time, then each row of U = T G^T),
+// which the scheduler places into the gaps between the step's 36 MFMAs.
+//   * filters: two register sets; a step's loads go out at its START and are first used a whole step later;
+//   * activations: chunk c+3 is requested after the second K step's filter loads (so no filter wait stands behind a young
+//     HBM request: vmcnt retires in order) and goes to LDS between the two K steps of the next phase;
+//   * all global memory through buffer descriptors: wave-uniform byte offset in a scalar register + one 32-bit per-lane
+//     offset, rows past the batch read as zero and are never stored (hardware range check): no `n < batch` branches.
+// FLAGS (experiments, tools/wino_lab.hip): 1 = no scheduling barrier between the MFMA block and the V production,
+//   2 = persistent workgroups (grid = resident count, loop over board groups), 4 = explicit MFMA / VALU / LDS-read groups.
+// ---------------------------------------------------------------------------------------------------
+// yv[0..5] = G x for one column x = (x0, x1, x2): the 6x3 filter transform of F(4x4, 3x3)
+__device__ __forceinline__ void filt6(float x0, float x1, float x2, float (&yv)[6]) {
+    const float t = x0 + x2;
+    const float p = x0 * (1.0f / 24.0f) + x2 * (1.0f / 6.0f), q = x1 * (1.0f / 12.0f);
+    yv[0] = x0 * 0.25f;
+    yv[1] = (t + x1) * (-1.0f / 6.0f);
+    yv[2] = (t - x1) * (-1.0f / 6.0f);
+    yv[3] = p + q;
+    yv[4] = p - q;
+    yv[5] = x2;
+}
+
+constexpr int G9_FLOATS = 16 * 4 * 2 * 64 * 4 + 16 * 4 * 64;      // G8[s][kb][2][lane][4] (taps 0..7) + G1[s][kb][lane] (tap 8)
+
+template <int H, int W, int FLAGS, int TAIL = 0>
+__global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* __restrict__ x, const float* __restrict__ wts,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ res, float* __restrict__ y, int batch,
+                                                                  int relu, const unsigned* __restrict__ batch_dev, TailArgs ta) {
+    constexpr bool PERSIST = (FLAGS & 2) != 0;
+    // batch_dev != null: the number of boards is on the device (the engine's leaf count of this round), `batch` is the
+    // capacity the grid was sized for; workgroups past the real count leave at once
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+    }
+    const int ngroups = (batch + NIMG2 - 1) / NIMG2;
+    if ((int)blockIdx.x >= ngroups) return;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS2];
+    float* const in_buf = lds;                        // [2][IN_BUF2]
+    float* const v_buf = lds + 2 * IN_BUF2;           // [2 phases][2 groups][V_G2]
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c_sub = lane >> 4, tl = lane & 15;
+    const int gl = wave & 1, wa = wave >> 1;          // producer role: group of the chunk, transform rows 3wa..3wa+2
+    const int kb = wave;                              // consumer role: output channels 16kb..16kb+15
+
+    for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;    // borders stay zero for the whole kernel
+
+    int ldst[2];
+    unsigned xoff[2];                                 // bytes
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int f = tid + NTHR2 * it;
+        const int b = f >> 7, rem = f & 127;
+        const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
+        ldst[it] = (g2 * 4 + cs) * CS2 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
+        xoff[it] = (unsigned)(b * 4096 + rem * 4) * 4u;
+    }
+    const int patch0 = (gl * 4 + c_sub) * CS2 + board_off(tl >> 2) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
+    const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
+    const unsigned act_bytes = (unsigned)batch * 16384u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (y && !TAIL) ? act_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wts, 0, (unsigned)G9_FLOATS * 4u, 0x00020000);
+    const int wlane16 = lane * 16, wlane4 = lane * 4;
+    const int ooff = ((tl >> 2) * 4096 + c_sub * 16 + (tl & 3) * 4) * 4;   // bytes: this lane's board, channel slot and tile
+    const int tile = tl & 3, ty = tile >> 1, tx = tile & 1;
+
+    auto group = [&](const int grp) {
+        const int n0 = grp * NIMG2;
+        // the filters are the same for every board group: keep the optimiser from hoisting the first K step's loads and
+        // transforms out of the persistent loop (36 registers held across everything else)
+        int wbase = kb * 2048;
+        if (PERSIST) asm volatile("" : "+s"(wbase));
+        f4 acc[36];
+#pragma unroll
+        for (int q = 0; q < 36; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+        f4 pre[2];
+        auto gload_to = [&](int chunk, f4 (&dst)[2]) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xoff[it], n0 * 16384 + chunk * 2048, 2));
+        };
+        auto lstore_from = [&](float* buf, const f4 (&src)[2]) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = src[it][j];
+        };
+        auto produce = [&](int c) {
+            const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
+            float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
+            float wr[3][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
+                const float st = 4.0f * e0 - 5.0f * e2 + e4;
+                if (wa == 0) {
+                    const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                    wr[0][j] = st;
+                    wr[1][j] = p + q;
+                    wr[2][j] = p - q;
+                } else {
+                    const float p = e3 - e1, q = 2.0f * (e2 - e0);
+                    wr[0][j] = p + q;
+                    wr[1][j] = p - q;
+                    wr[2][j] = st;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+                const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
+                vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
+                vd[(r * 6 + 1) * 64] = p + q;
+                vd[(r * 6 + 2) * 64] = p - q;
+                vd[(r * 6 + 3) * 64] = p2 + q2;
+                vd[(r * 6 + 4) * 64] = p2 - q2;
+                vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
+            }
+        };
+        // ---- A operand: the 3x3 filters of K step s for this lane's (out channel, in channel), two register sets ----
+        f4 gq0[2], gq1[2];
+        float gq2[2];
+        auto wload = [&](int s) {
+            gq0[s & 1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane16, wbase + s * 8192, 0));
+            gq1[s & 1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane16, wbase + s * 8192 + 1024, 0));
+            gq2[s & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wlane4, (wbase >> 3) + 16 * 8192 + s * 1024, 0));
+        };
+        auto mma1 = [&](const float* vg, int p, float av) {
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vg[p * 64 + lane], acc[p], 0, 0, 0);
+        };
+        // one K step = one group of 4 input channels: 36 MFMAs; `chunk` >= 0: request that activation chunk behind the filters
+        auto kstep = [&](const float* vg, int s, int chunk) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < 16) wload(s + 1);
+            if (chunk >= 0) gload_to(chunk, pre);
+            __builtin_amdgcn_sched_barrier(0);            // the loads stay here, a whole K step ahead of their first use
+            const f4 gn0 = gq0[s & 1], gn1 = gq1[s & 1];
+            const float gn2 = gq2[s & 1];
+            const float g[3][3] = { { gn0[0], gn0[1], gn0[2] }, { gn0[3], gn1[0], gn1[1] }, { gn1[2], gn1[3], gn2 } };
+            float uu[6];
+            filt6(g[0][0] * 0.25f, g[0][1] * 0.25f, g[0][2] * 0.25f, uu);      // row 0 of T = G g is g[0][.] / 4
+#pragma unroll
+            for (int b = 0; b < 6; ++b) mma1(vg, b, uu[b]);
+            {   // rows 1, 2
+                float t1[3], t2[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float t = g[0][j] + g[2][j];
+                    t1[j] = (t + g[1][j]) * (-1.0f / 6.0f);
+                    t2[j] = (t - g[1][j]) * (-1.0f / 6.0f);
+                }
+                filt6(t1[0], t1[1], t1[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 6 + b, uu[b]);
+                filt6(t2[0], t2[1], t2[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 12 + b, uu[b]);
+            }
+            {   // rows 3, 4
+                float t3[3], t4[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float p = g[0][j] * (1.0f / 24.0f) + g[2][j] * (1.0f / 6.0f), q = g[1][j] * (1.0f / 12.0f);
+                    t3[j] = p + q;
+                    t4[j] = p - q;
+                }
+                filt6(t3[0], t3[1], t3[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 18 + b, uu[b]);
+                filt6(t4[0], t4[1], t4[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 24 + b, uu[b]);
+            }
+            filt6(g[2][0], g[2][1], g[2][2], uu);                               // row 5 of T is g[2][.]
+#pragma unroll
+            for (int b = 0; b < 6; ++b) mma1(vg, 30 + b, uu[b]);
+            if (FLAGS & 4) {
+#pragma unroll
+                for (int i = 0; i < 36; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // 3 VALU
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 LDS read
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto phase = [&](int c) {
+            const float* vs = v_buf + (c & 1) * 2 * V_G2;
+            kstep(vs, 2 * c, -1);
+            if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
+            kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1);
+            if (FLAGS & 1) __builtin_amdgcn_sched_barrier(0x2);                  // (experiment) VALU may cross
+            if (c + 1 < 8) produce(c + 1);
+            __syncthreads();
+        };
+
+        const int plane0 = n0 * 16384 + kb * 4096;        // bytes; + ooff
+        f4 rres[4][4];
+        auto rload = [&](int r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ooff, plane0 + r * 1024 + i * 256, 2));
+        };
+
+        {   // the first two chunks are requested together: one HBM round trip before the first V can be built, not two
+            f4 first[2];
+            gload_to(0, first);
+            gload_to(1, pre);
+            wload(0);
+            __syncthreads();                               // zero fill done / the previous group's LDS reads are over
+            lstore_from(in_buf, first);
+            lstore_from(in_buf + IN_BUF2, pre);
+        }
+        gload_to(2, pre);
+        __syncthreads();
+        produce(0);
+        __syncthreads();
+        for (int c = 0; c < 8; ++c) phase(c);
+
+        // ---- inverse transform in registers + epilogue ----
+        rload(0);
+        rload(1);
+        constexpr int OC = 3;                              // TAIL: 2 policy + 1 value head channels
+        float hp[TAIL ? OC : 1][4][4];                     // TAIL: this lane's share of the 1x1 head convolutions (its 4 channels)
+        if (TAIL) {
+#pragma unroll
+            for (int o = 0; o < OC; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hp[TAIL ? o : 0][i][j] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_barrier(0);
+            float m[6][6];
+#pragma unroll
+            for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = acc[p][r];
+            float o[4][4];
+            inverse_transform(m, o);
+            const int k = 16 * kb + 4 * c_sub + r;
+            const float sc = scale[k], sh = shift[k];
+            float hwk[OC];
+            if (TAIL) {
+#pragma unroll
+                for (int oc = 0; oc < OC; ++oc) hwk[oc] = ta.hw[oc * 64 + k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f4 v;
+                const f4 rv = rres[r][i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = o[i][j] * sc + sh + rv[j];
+                    if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                    if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;       // cells off the board stay zero
+                }
+                if (TAIL) {
+#pragma unroll
+                    for (int oc = 0; oc < OC; ++oc)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hp[TAIL ? oc : 0][i][j] += hwk[oc] * v[j];
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ooff, plane0 + r * 1024 + i * 256, 2);
+                }
+            }
+            if (r + 2 < 4) rload(r + 2);
+        }
+        if (!TAIL) return;
+
+        // ---- head convolutions fused behind the LAST trunk convolution: only the ReLU'd head maps are written ----
+        // Every lane holds the head-convolution partial sums of its 4 channels for its 16 cells; the 16 partials of a cell
+        // (4 waves x 4 lane groups) are summed through LDS in a fixed order.  The LDS images are dead by now.
+        constexpr int PROW = OC * 256 + 16;                // partial row stride: 32 lanes of a bank group -> 32 banks
+        float* const part = lds;                           // [kb * 4 + c_sub][o][(i * 4 + j) * 16 + tl]
+        float* const maps = lds + 16 * PROW;               // [board][o * HW + row * W + col]
+        constexpr int HW = H * W;
+#pragma unroll
+        for (int oc = 0; oc < OC; ++oc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[(kb * 4 + c_sub) * PROW + oc * 256 + (i * 4 + j) * 16 + tl] = hp[TAIL ? oc : 0][i][j];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < OC; ++q) {
+            const int idx = tid + NTHR2 * q;               // (o, cell) pairs: 768 per workgroup
+            const int oc = idx >> 8, cp = idx & 255;
+            float sum = 0.0f;
+#pragma unroll
+            for (int rw16 = 0; rw16 < 16; ++rw16) sum += part[rw16 * PROW + oc * 256 + cp];
+            const int ij = cp >> 4, t16 = cp & 15;
+            const int b = t16 >> 2, tl4 = t16 & 3;
+            const int row = 4 * (tl4 >> 1) + (ij >> 2), col = 4 * (tl4 & 1) + (ij & 3);
+            sum += ta.hb[oc];
+            if (row < H && col < W) maps[b * (OC * HW) + oc * HW + row * W + col] = sum > 0.0f ? sum : 0.0f;
+        }
+        __syncthreads();
+        for (int i = tid; i < NIMG2 * OC * HW; i += NTHR2) {
+            const int b = i / (OC * HW);
+            if (n0 + b < batch) ta.maps_out[(size_t)n0 * (OC * HW) + i] = maps[i];
+        }
+        if (PERSIST) {                                     // the next group needs its zero borders back
+            __syncthreads();
+            for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;
+        }
+    };
+    if (PERSIST) {
+        for (int grp = (int)blockIdx.x; grp < ngroups; grp += (int)gridDim.x) group(grp);
+    } else {
+        group((int)blockIdx.x);
+    }
+}
+
+template <int FLAGS>
+static int sprl_wino_conv64_v4_launch(const float* x, const float* wts, const float* scale, const float* shift, const float* res,
+                                      float* y, int batch, int relu, const unsigned* batch_dev, void* stream) {
+    const int ngroups = (batch + NIMG2 - 1) / NIMG2;
+    const int grid = (FLAGS & 2) ? (ngroups < 512 ? ngroups : 512) : ngroups;
+    hipLaunchKernelGGL((wino_conv64_v4_kernel<8, 8, FLAGS>), dim3((unsigned)grid), dim3(NTHR2), 0, (hipStream_t)stream, x, wts,
+                       scale, shift, res, y, batch, relu, batch_dev, TailArgs{});
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -92,7 +92,7 @@ def test_in_process_loop_hot_swaps_the_model(tmp_path):
     assert lo.shape == (2, 7) and va.shape == (2, 1)
 
 
-@pytest.mark.parametrize("game", ["c4", "othello", "go"])
+@pytest.mark.parametrize("game", ["c4", "othello", "go", "go9"])
 def test_compact_record_format_v2_roundtrip(game, tmp_path):
     """the compact on-disk form expands to exactly the reference arrays."""
     from sprl_amd import records_v2

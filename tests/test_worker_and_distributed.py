@@ -60,13 +60,29 @@ def test_worker_covers_several_tasks_with_reference_file_layout(emu, tmp_path):
     assert (d2.view(np.uint32) == ora["dists"][split:].view(np.uint32)).all()
 
 
-def test_pack_unpack_roundtrip(emu):
-    from sprl_amd.distributed import pack_records, unpack_records
-    _, rec, _ = parity.run_engine(emu, "othello", 2, concurrent_games=2, num_traversals=16, seed=9)
-    u = unpack_records(pack_records(rec))
-    assert (u["boards"] == rec.boards).all() and (u["movers"] == rec.movers).all()
+@pytest.mark.parametrize("game,kw", [("othello", dict(num_traversals=16)), ("c4", dict(num_traversals=16)),
+                                     ("go", dict(num_traversals=20)),
+                                     ("go9", dict(num_traversals=20)),        # 81 cells: 2 words per bit set
+                                     ("go19", dict(num_traversals=12))])      # 361 cells: 6 words
+def test_pack_unpack_roundtrip(emu, game, kw):
+    """The wire format of the record gather carries every board size (the 64-cell limit broke Go 9x9 / 19x19)."""
+    from sprl_amd.distributed import pack_records, unpack_records, section_offsets
+    ngames = 1 if game == "go19" else 2
+    cfg = E.default_config(game, emu, concurrent_games=ngames, seed=9, **kw)
+    eng = E.Engine(cfg, emu)
+    eng.set_model("random")
+    rec = eng.run(ngames)
+    eng.close()
+    buf = pack_records(rec)
+    u = unpack_records(buf)
+    assert u["cells"] == rec.cells and u["words"] == (rec.cells + 63) // 64 and u["history"] == rec.history
+    assert u["boards"].shape == rec.boards.shape and (u["boards"] == rec.boards).all() and (u["movers"] == rec.movers).all()
     assert (u["pdfs"].view(np.uint32) == rec.pdfs.view(np.uint32)).all()
     assert (u["ply_offset"] == rec.ply_offset).all() and (u["winners"] == rec.winners).all()
+    off = section_offsets(rec.num_games, rec.total_plies, rec.actions, u["words"])
+    assert buf.size == off["total"] and all(v % 16 == 0 for v in off.values())
+    with pytest.raises(ValueError):
+        unpack_records(buf[:-16])
 
 
 RANK_SCRIPT = r"""
@@ -79,7 +95,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 lib = E.load_library({emu!r})
 games = 3
-cfg = E.default_config("c4", lib, concurrent_games=2, num_traversals=24, seed=21, stream_base=1 + rank * games)
+cfg = E.default_config({game!r}, lib, concurrent_games=2, num_traversals={trav}, seed=21, stream_base=1 + rank * games)
 eng = E.Engine(cfg, lib); eng.set_model("random")
 rec = eng.run(games)
 shards = gather_records(rec, dist)
@@ -89,19 +105,24 @@ dist.barrier(); dist.destroy_process_group()
 """
 
 
-def test_two_rank_game_sharding_gloo(emu, tmp_path):
+@pytest.mark.parametrize("game,trav,port", [("c4", 24, 29533), ("othello", 16, 29534), ("go9", 20, 29535)])
+def test_two_rank_game_sharding_gloo(emu, tmp_path, game, trav, port):
     """world_size 2 on CPU: each rank plays its own shard (disjoint RNG streams); rank 0 ends up with both
     shards, which together equal oracle games 1..6 in order."""
     out = str(tmp_path / "gathered.npz")
     script = tmp_path / "rank.py"
-    script.write_text(RANK_SCRIPT.format(root=ROOT, emu=os.path.join(EMU_DIR, "libsprl_emu.so"), out=out))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    script.write_text(RANK_SCRIPT.format(root=ROOT, emu=os.path.join(EMU_DIR, "libsprl_emu.so"), out=out, game=game, trav=trav))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     assert [p.wait(timeout=240) for p in procs] == [0, 0]
     z = np.load(out)
-    cfg = po.make_config(po.GAME_C4, 24, math_mode=po.MATH_PORTABLE)
+    ogame = {"c4": po.GAME_C4, "othello": po.GAME_OTHELLO, "go9": po.GAME_GO9}[game]
+    cfg = po.make_config(ogame, trav, math_mode=po.MATH_PORTABLE)
     ora = po.selfplay(cfg, 6, 21, 1, True)
+    nsym = 2 if game == "c4" else 8
     pdfs = np.concatenate([z["r0_pdfs"], z["r1_pdfs"]])
-    # oracle pdf rows are symmetrised x2; symmetry 0 (identity) rows are the compact ones
-    assert (pdfs.view(np.uint32) == ora["dists"][0::2].view(np.uint32)).all()
-    assert (np.concatenate([z["r0_boards"], z["r1_boards"]]) == ora["boards"][0::2]).all()
+    # oracle rows are symmetrised x nsym; symmetry 0 (identity) rows are the compact ones
+    assert (pdfs.view(np.uint32) == ora["dists"][0::nsym].view(np.uint32)).all()
+    cells = z["r0_boards"].shape[1]
+    assert (np.concatenate([z["r0_boards"], z["r1_boards"]]) == ora["boards"][0::nsym][:, :cells]).all()
+    assert (np.concatenate([z["r0_winners"], z["r1_winners"]]).size == 6)
