@@ -44,39 +44,68 @@ def algorithmic_bytes_per_traversal(st, A=65, mask_bytes=8, board_bytes=64, s_in
 
 
 def _cpu_worker(args):
-    """One single-threaded reference worker process: the reference's selfPlay + GridNetwork on LibTorch-CPU."""
+    """One single-threaded reference worker process: the reference's selfPlay + GridNetwork on LibTorch-CPU,
+    `games` games one after the other (each timed), like a reference worker's iteration (OTHWorker.cpp:17: 3 games)."""
     model, games, trav, stream = args
     os.environ["OMP_NUM_THREADS"] = "1"
     os.environ["MKL_NUM_THREADS"] = "1"
     import torch
     torch.set_num_threads(1)
     from oracle import pyref
-    t0 = time.time()
-    r = pyref.selfplay("othello", 0, games, trav, 8, 4, 0.25, 0.3, 4242, stream, True, model_path=model)
-    return time.time() - t0, games, r["evals"], len(r["players"])
+    times, evals, plies = [], 0, 0
+    for g in range(games):
+        t0 = time.time()
+        r = pyref.selfplay("othello", 0, 1, trav, 8, 4, 0.25, 0.3, 4242, stream + g, True, model_path=model)
+        times.append(time.time() - t0)
+        evals += r["evals"]
+        plies += len(r["players"]) // 8
+    return times, evals, plies
 
 
-def cpu_baseline(model_path, traversals, budget_games_per_core=1):
-    """Reference CPU path timed on this box's host cores (bounded sample).  kind = "reference" when the prebuilt
-    oracle/_ref library (the reference's own sources compiled in place) travelled with the repo, else the
-    oracle ("port") with a LibTorch-CPU forward callback."""
+def host_cores():
+    """Cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job a share of the host, not the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(model_path, traversals, games_per_process=3, max_processes=0):
+    """Reference CPU path timed on this box's host cores, SURVEY section 8(d) protocol: one single-threaded process per
+    usable host core (count stated), >= 3 games per process, median games/s per core + aggregate.  kind = "reference"
+    when the prebuilt oracle/_ref library (the reference's own sources compiled in place) travelled with the repo, else
+    the oracle ("port") with a LibTorch-CPU forward callback."""
     import multiprocessing as mp
+    import statistics
     from oracle import pyref
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = host_cores()
+    if max_processes > 0:
+        cores = min(cores, max_processes)
     if pyref.available(True):
         ctx = mp.get_context("spawn")
         t0 = time.time()
         with ctx.Pool(cores) as pool:
-            res = pool.map(_cpu_worker, [(model_path, budget_games_per_core, traversals, 1000 + i) for i in range(cores)])
+            res = pool.map(_cpu_worker, [(model_path, games_per_process, traversals, 1000 + 16 * i) for i in range(cores)])
         wall = time.time() - t0
-        games = sum(r[1] for r in res)
-        evals = sum(r[2] for r in res)
-        per_proc = max(r[0] for r in res)
-        return {"value": games / per_proc, "unit": "games/s", "cores": cores, "kind": "reference",
-                "sample": f"{cores} single-thread processes x {budget_games_per_core} game(s), Othello {traversals} it/move, "
-                          f"batch 8/queue 4, same traced 2x64 CNN on LibTorch-CPU, -O3 -DNDEBUG; slowest process "
-                          f"{per_proc:.1f}s (pool wall {wall:.1f}s), {evals} network evals",
-                "games_per_sec_per_core": games / per_proc / cores, "evals_per_sec": evals / per_proc}
+        games = cores * games_per_process
+        evals = sum(r[1] for r in res)
+        per_core = [len(r[0]) / sum(r[0]) for r in res]          # games/s of each process while it was playing
+        med = statistics.median(per_core)
+        busy = max(sum(r[0]) for r in res)                       # the slowest process bounds the iteration
+        return {"value": games / busy, "unit": "games/s", "cores": cores, "kind": "reference",
+                "sample": f"{cores} single-thread processes (all usable host cores) x {games_per_process} games, Othello {traversals} "
+                          f"it/move, batch 8/queue 4, same traced 2x64 CNN on LibTorch-CPU, g++ -O3 -DNDEBUG; slowest process "
+                          f"{busy:.1f}s (pool wall incl. start-up {wall:.1f}s), {evals} network evals",
+                "games_per_sec_per_core_median": med, "games_per_sec_per_core_min": min(per_core),
+                "games_per_sec_per_core_max": max(per_core), "aggregate_of_per_core_rates": sum(per_core),
+                "evals_per_sec": evals / busy, "games_per_process": games_per_process,
+                "reference_deployment_cores": 384,               # README.md:124-128, OTHWorker.cpp:13
+                "reference_deployment_games_per_sec": 384 * med}
     # fallback: the oracle with a torch-CPU forward (scalar port, 1 core)
     import torch
     from oracle import pyoracle as po
@@ -327,7 +356,12 @@ def main():
                 mp_model = trace_to_file(make_network("othello", args.blocks, args.channels, seed=0),
                                          os.path.join(tmpdir, "traced_cpu.pt"), "othello")
             try:
-                out["cpu_baseline"] = cpu_baseline(mp_model, args.traversals)
+                cb = cpu_baseline(mp_model, args.traversals)
+                if cb.get("value"):
+                    cb["gpu_over_host_cores"] = out["value"] / cb["value"]           # 1 MI355X vs all usable host cores
+                if cb.get("reference_deployment_games_per_sec"):
+                    cb["gpu_over_reference_deployment"] = out["value"] / cb["reference_deployment_games_per_sec"]
+                out["cpu_baseline"] = cb
             except Exception as exc:  # the baseline is reported, never the target: do not lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {exc}"}

@@ -59,7 +59,9 @@ typedef struct sprl_config {
     int32_t use_symmetry;      /* symmetrizer != nullptr */
     int32_t add_noise;         /* runIteration's addNoise */
     int32_t mask_frame;        /* SPRL_MASK_* */
-    int32_t node_cap;          /* nodes per game arena (1 KiB each), <= 65535; 0 = default */
+    int32_t node_cap;          /* nodes per game arena (1 KiB each; Go 9x9 2 KiB, 19x19 5.5 KiB); 0 = default.  Othello / Connect Four /
+                                  Go 7x7: < 2^24 (child indices widen from 16 to 24 bits above 65535), nodes of pruned siblings are
+                                  reused, default 10 x num_traversals + 2048.  Boards wider than 8x8: <= 65535 */
     int32_t spare_arenas;      /* arenas kept free for compaction; 0 = default */
     int32_t max_plies;         /* record capacity per game; 0 = default */
     uint64_t seed;             /* game g uses Random(seed, stream_base + g) (utils/random.hpp:92-103); a later run on the same
@@ -72,7 +74,7 @@ typedef struct sprl_config {
                                   when the mean backed-up value of its decision node (sum W / sum N over its edges) is below
                                   -resign_threshold; the ply's sample is kept, the opponent wins */
     int32_t resign_min_ply;    /* no resignation before this ply */
-    int32_t reserved_;
+    int32_t no_recycle;        /* 1: never reuse the nodes of pruned siblings (bump allocation + compaction only; tests) */
 } sprl_config;
 
 /* Fills `cfg` with the reference worker's constants for `game` (OTHWorker.cpp:24-28, C4Worker.cpp:23-27,
@@ -155,6 +157,7 @@ typedef struct sprl_stats {
     /* trunk-convolution kernel of the hand-written CNN (HIP events around every launch; profile=1) */
     double conv_ms;
     int64_t conv_launches, conv_boards;
+    int64_t nodes_recycled;    /* node creations served from pruned siblings' nodes instead of fresh arena space */
 } sprl_stats;
 int sprl_engine_stats(sprl_engine* e, sprl_stats* out);
 

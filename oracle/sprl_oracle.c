@@ -26,7 +26,7 @@ static geom_t geom(int game) {
         g.rows = 6; g.cols = 7; g.cells = 42; g.A = 7; g.nsym = 2; g.hist = 1;
     } else if (game == ORC_GAME_GO7) {   /* games/GoNode.hpp:16-22: 7x7, 8-ply history, 49 + pass */
         g.rows = 7; g.cols = 7; g.cells = 49; g.A = 50; g.nsym = 8; g.hist = 8;
-    } else if (game == ORC_GAME_GO9) {   /* the same rules at width 9 (BASELINE config 4; not reference-pinned) */
+    } else if (game == ORC_GAME_GO9) {   /* the same rules at width 9, komi 7.5 (BASELINE config 4); pinned by tests/golden/g_go9.npz = the reference compiled with only GO_BOARD_WIDTH / GO_KOMI changed */
         g.rows = 9; g.cols = 9; g.cells = 81; g.A = 82; g.nsym = 8; g.hist = 8;
     } else if (game == ORC_GAME_GO19) {  /* width 19 (BASELINE config 5) */
         g.rows = 19; g.cols = 19; g.cells = 361; g.A = 362; g.nsym = 8; g.hist = 8;

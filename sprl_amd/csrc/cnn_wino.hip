@@ -654,10 +654,12 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
 #pragma unroll
         for (int q = 0; q < 36; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
         f4 pre[2];
+        // per-lane byte offsets carry the board (so the range check drops boards past the batch whatever the scalar offset adds)
+        const int xvoff[2] = { (int)xoff[0] + n0 * 16384, (int)xoff[1] + n0 * 16384 };
         auto gload_to = [&](int chunk, f4 (&dst)[2]) {
 #pragma unroll
             for (int it = 0; it < 2; ++it)
-                dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xoff[it], n0 * 16384 + chunk * 2048, 2));
+                dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[it], chunk * 2048, 2));
         };
         auto lstore_from = [&](float* buf, const f4 (&src)[2]) {
 #pragma unroll
@@ -669,9 +671,24 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
             const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
             float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
             float wr[3][6];
+            constexpr float C6 = -1.0f / 6.0f, C24 = 1.0f / 24.0f;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
+                if (FLAGS & 16) {                         // rows scaled by (1/4, -1/6, -1/6, 1/24, 1/24, 1)
+                    if (wa == 0) {
+                        const float p = C6 * e4 - 4.0f * C6 * e2, q = C6 * e3 - 4.0f * C6 * e1;
+                        wr[0][j] = e0 - 1.25f * e2 + 0.25f * e4;
+                        wr[1][j] = p + q;
+                        wr[2][j] = p - q;
+                    } else {
+                        const float p = C24 * (e3 - e1), q = 2.0f * C24 * (e2 - e0);
+                        wr[0][j] = p + q;
+                        wr[1][j] = p - q;
+                        wr[2][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                    }
+                    continue;
+                }
                 const float st = 4.0f * e0 - 5.0f * e2 + e4;
                 if (wa == 0) {
                     const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
@@ -685,16 +702,43 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
                     wr[2][j] = st;
                 }
             }
+            float vv[18];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+                if (FLAGS & 16) {                         // columns scaled the same way
+                    const float p = C6 * w4 - 4.0f * C6 * w2, q = C6 * w3 - 4.0f * C6 * w1, p2 = C24 * (w4 - w2), q2 = 2.0f * C24 * (w3 - w1);
+                    vv[r * 6 + 0] = w0 - 1.25f * w2 + 0.25f * w4;
+                    vv[r * 6 + 1] = p + q;
+                    vv[r * 6 + 2] = p - q;
+                    vv[r * 6 + 3] = p2 + q2;
+                    vv[r * 6 + 4] = p2 - q2;
+                    vv[r * 6 + 5] = 4.0f * w1 - 5.0f * w3 + w5;
+                    continue;
+                }
                 const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
-                vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
-                vd[(r * 6 + 1) * 64] = p + q;
-                vd[(r * 6 + 2) * 64] = p - q;
-                vd[(r * 6 + 3) * 64] = p2 + q2;
-                vd[(r * 6 + 4) * 64] = p2 - q2;
-                vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
+                vv[r * 6 + 0] = 4.0f * w0 - 5.0f * w2 + w4;
+                vv[r * 6 + 1] = p + q;
+                vv[r * 6 + 2] = p - q;
+                vv[r * 6 + 3] = p2 + q2;
+                vv[r * 6 + 4] = p2 - q2;
+                vv[r * 6 + 5] = 4.0f * w1 - 5.0f * w3 + w5;
+            }
+            if (FLAGS & 8) {
+                // V[group][p / 4][lane][p % 4]: this thread owns positions 18 wa .. 18 wa + 17 = four whole quads and half of quad 4
+                float* vq = v_buf + (c & 1) * 2 * V_G2 + gl * V_G2 + lane * 4;
+                if (wa == 0) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) *(f4*)(vq + q4 * 256) = (f4){ vv[4 * q4], vv[4 * q4 + 1], vv[4 * q4 + 2], vv[4 * q4 + 3] };
+                    *(f2*)(vq + 4 * 256) = (f2){ vv[16], vv[17] };
+                } else {
+                    *(f2*)(vq + 4 * 256 + 2) = (f2){ vv[0], vv[1] };
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) *(f4*)(vq + (5 + q4) * 256) = (f4){ vv[2 + 4 * q4], vv[3 + 4 * q4], vv[4 + 4 * q4], vv[5 + 4 * q4] };
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 18; ++q) vd[q * 64] = vv[q];
             }
         };
         // ---- A operand: the 3x3 filters of K step s for this lane's (out channel, in channel), two register sets ----
@@ -705,19 +749,77 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
             gq1[s & 1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane16, wbase + s * 8192 + 1024, 0));
             gq2[s & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wlane4, (wbase >> 3) + 16 * 8192 + s * 1024, 0));
         };
+        f4 bq[9];                                         // FLAGS & 8: the step's B operands, one 16-byte LDS read per four positions
         auto mma1 = [&](const float* vg, int p, float av) {
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vg[p * 64 + lane], acc[p], 0, 0, 0);
+            const float b = (FLAGS & 8) ? bq[p >> 2][p & 3] : vg[p * 64 + lane];
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[p], 0, 0, 0);
         };
         // one K step = one group of 4 input channels: 36 MFMAs; `chunk` >= 0: request that activation chunk behind the filters
         auto kstep = [&](const float* vg, int s, int chunk) {
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < 16) wload(s + 1);
-            if (chunk >= 0) gload_to(chunk, pre);
+            if (s + 1 < 16 && !(FLAGS & 128)) wload(s + 1);
+            if (chunk >= 0 && !(FLAGS & 1024)) gload_to(chunk, pre);
             __builtin_amdgcn_sched_barrier(0);            // the loads stay here, a whole K step ahead of their first use
+            if (FLAGS & 8) {
+#pragma unroll
+                for (int q4 = 0; q4 < 9; ++q4) bq[q4] = *(const f4*)(vg + q4 * 256 + lane * 4);
+            }
             const f4 gn0 = gq0[s & 1], gn1 = gq1[s & 1];
             const float gn2 = gq2[s & 1];
             const float g[3][3] = { { gn0[0], gn0[1], gn0[2] }, { gn0[3], gn1[0], gn1[1] }, { gn1[2], gn1[3], gn2 } };
             float uu[6];
+            if (FLAGS & 16) {
+                // U' = G' g G'^T, G' = [[1,0,0],[1,1,1],[1,-1,1],[1,2,4],[1,-2,4],[0,0,1]] (the row scales live in V): 6 operations
+                // per 6-vector instead of 11 -> 18 + 36 = 54 per K step
+                auto f6 = [](float x0, float x1, float x2, float (&yv)[6]) {
+                    const float t = x0 + x2, p = x0 + 4.0f * x2;
+                    yv[0] = x0;
+                    yv[1] = t + x1;
+                    yv[2] = t - x1;
+                    yv[3] = p + 2.0f * x1;
+                    yv[4] = p - 2.0f * x1;
+                    yv[5] = x2;
+                };
+                f6(g[0][0], g[0][1], g[0][2], uu);                               // row 0 of T' = g[0][.]
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, b, uu[b]);
+                float ta[3], tb[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float t = g[0][j] + g[2][j];
+                    ta[j] = t + g[1][j];
+                    tb[j] = t - g[1][j];
+                }
+                f6(ta[0], ta[1], ta[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 6 + b, uu[b]);
+                f6(tb[0], tb[1], tb[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 12 + b, uu[b]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float p = g[0][j] + 4.0f * g[2][j];
+                    ta[j] = p + 2.0f * g[1][j];
+                    tb[j] = p - 2.0f * g[1][j];
+                }
+                f6(ta[0], ta[1], ta[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 18 + b, uu[b]);
+                f6(tb[0], tb[1], tb[2], uu);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 24 + b, uu[b]);
+                f6(g[2][0], g[2][1], g[2][2], uu);                               // row 5 of T' = g[2][.]
+#pragma unroll
+                for (int b = 0; b < 6; ++b) mma1(vg, 30 + b, uu[b]);
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
+            if (FLAGS & 64) {                             // ablation: no filter transform, 36 MFMAs on raw taps
+#pragma unroll
+                for (int p = 0; p < 36; ++p) mma1(vg, p, g[(p / 3) % 3][p % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             filt6(g[0][0] * 0.25f, g[0][1] * 0.25f, g[0][2] * 0.25f, uu);      // row 0 of T = G g is g[0][.] / 4
 #pragma unroll
             for (int b = 0; b < 6; ++b) mma1(vg, b, uu[b]);
@@ -770,23 +872,33 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
             if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
             kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1);
             if (FLAGS & 1) __builtin_amdgcn_sched_barrier(0x2);                  // (experiment) VALU may cross
-            if (c + 1 < 8) produce(c + 1);
+            if (c + 1 < 8 && !(FLAGS & 256)) produce(c + 1);
             __syncthreads();
         };
 
-        const int plane0 = n0 * 16384 + kb * 4096;        // bytes; + ooff
+        // Output rows: per-lane offset + an IMMEDIATE row offset, scalar offset 0.  With a scalar-register offset the compiler
+        // assumes a 16-byte buffer store needs no wait state before its data registers are overwritten (LLVM createsVALUHazard:
+        // "hazard only exists if the instruction is not using a register in the soffset field") and schedules a v_pk_mov into
+        // them right behind the store; on gfx950 that corrupted dword 1 of lanes 12-15 of every 16 (found with tools/wino_lab).
+        const int ovoff = ooff + n0 * 16384 + kb * 4096;
         f4 rres[4][4];
         auto rload = [&](int r) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ooff, plane0 + r * 1024 + i * 256, 2));
+                rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, 2));
         };
 
+        unsigned long long* const stamps = (FLAGS & 32) ? (unsigned long long*)ta.maps_out + (size_t)grp * 16 : nullptr;
+        auto stamp = [&](int slot) {
+            if ((FLAGS & 32) && tid == 0) stamps[slot] = __builtin_amdgcn_s_memtime();
+        };
+        stamp(0);
         {   // the first two chunks are requested together: one HBM round trip before the first V can be built, not two
             f4 first[2];
             gload_to(0, first);
             gload_to(1, pre);
             wload(0);
+            if (FLAGS & 128) { gq0[1] = gq0[0]; gq1[1] = gq1[0]; gq2[1] = gq2[0]; }
             __syncthreads();                               // zero fill done / the previous group's LDS reads are over
             lstore_from(in_buf, first);
             lstore_from(in_buf + IN_BUF2, pre);
@@ -795,8 +907,19 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
         __syncthreads();
         produce(0);
         __syncthreads();
-        for (int c = 0; c < 8; ++c) phase(c);
+        stamp(1);
+        for (int c = 0; c < 8; ++c) {
+            phase(c);
+            stamp(2 + c);
+        }
 
+        if (FLAGS & 512) {                                // ablation: no output stage
+            float sum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 36; ++q) sum += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+            if (sum == 123.456f) y[tid] = sum;
+            return;
+        }
         // ---- inverse transform in registers + epilogue ----
         rload(0);
         rload(1);
@@ -841,11 +964,12 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
 #pragma unroll
                         for (int j = 0; j < 4; ++j) hp[TAIL ? oc : 0][i][j] += hwk[oc] * v[j];
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ooff, plane0 + r * 1024 + i * 256, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * 1024 + i * 256), 0, 2);
                 }
             }
             if (r + 2 < 4) rload(r + 2);
         }
+        stamp(10);
         if (!TAIL) return;
 
         // ---- head convolutions fused behind the LAST trunk convolution: only the ReLU'd head maps are written ----
@@ -894,11 +1018,13 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
 
 template <int FLAGS>
 static int sprl_wino_conv64_v4_launch(const float* x, const float* wts, const float* scale, const float* shift, const float* res,
-                                      float* y, int batch, int relu, const unsigned* batch_dev, void* stream) {
+                                      float* y, int batch, int relu, const unsigned* batch_dev, void* stream, float* stamps = nullptr) {
     const int ngroups = (batch + NIMG2 - 1) / NIMG2;
     const int grid = (FLAGS & 2) ? (ngroups < 512 ? ngroups : 512) : ngroups;
+    TailArgs ta{};
+    ta.maps_out = stamps;
     hipLaunchKernelGGL((wino_conv64_v4_kernel<8, 8, FLAGS>), dim3((unsigned)grid), dim3(NTHR2), 0, (hipStream_t)stream, x, wts,
-                       scale, shift, res, y, batch, relu, batch_dev, TailArgs{});
+                       scale, shift, res, y, batch, relu, batch_dev, ta);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -221,6 +221,7 @@ void add_slot_stats(const std::vector<GameCtl>& ctl, sprl_stats* out) {
         out->dup_hits += (int64_t)c.stats.dup_hits;
         out->nodes_created += (int64_t)c.stats.nodes_created;
         out->compactions += (int64_t)c.stats.compactions;
+        out->nodes_recycled += (int64_t)c.stats.nodes_recycled;
         out->cyc_total += (int64_t)c.stats.cyc_total;
         out->cyc_finish += (int64_t)c.stats.cyc_finish;
         out->cyc_move += (int64_t)c.stats.cyc_move;
@@ -295,7 +296,9 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
         return fail(SPRL_E_CONFIG, "num_traversals must exceed max_queue: a fresh root is queued max_queue times (SURVEY Q7), so "
                                    "the first move would be sampled from an all-zero visit count (NaN pdf in the reference)");
     if (cfg->stream_base < 1) return fail(SPRL_E_CONFIG, "stream_base must be >= 1 (stream 0 means 'pick one' in the reference)");
-    if (cfg->node_cap < 0 || cfg->node_cap > 65535) return fail(SPRL_E_CONFIG, "node_cap must be <= 65535");
+    const bool single_strip = cfg->game == SPRL_OTHELLO || cfg->game == SPRL_CONNECT_FOUR || cfg->game == SPRL_GO7;
+    if (cfg->node_cap < 0 || cfg->node_cap > (single_strip ? 0xFFFFFE : 65535))
+        return fail(SPRL_E_CONFIG, single_strip ? "node_cap must be < 2^24" : "node_cap must be <= 65535 for boards wider than 8x8");
     if (!(cfg->dir_alpha > 0.0f)) return fail(SPRL_E_CONFIG, "dir_alpha must be > 0");
     if (cfg->resign_threshold < 0.0f || cfg->resign_threshold >= 1.0f) return fail(SPRL_E_CONFIG, "resign_threshold must be in [0, 1)");
     std::string err;
@@ -335,10 +338,22 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.seed = cfg->seed;
     P.num_slots = cfg->concurrent_games;
     P.num_spare = cfg->spare_arenas > 0 ? cfg->spare_arenas : (cfg->concurrent_games / 64 > 8 ? cfg->concurrent_games / 64 : 8);
-    long cap = cfg->node_cap > 0 ? cfg->node_cap : (long)cfg->num_traversals * 52 + 1024;
-    if (cap > 65535) cap = 65535;
+    // Node recycling (single-strip kernel): an arena holds the live subtree + the garbage not yet reused, so its size follows
+    // the per-move budget, not the game length: 10 x traversals + 2048 nodes is ~2x the high-water mark measured over whole
+    // Othello / Connect Four / Go 7x7 games; compaction into a spare arena remains the fallback.
+    // Boards wider than 8x8 (multi-strip kernel): bump allocation + compaction, 16-bit child indices.
+    P.recycle = (single_strip && cfg->max_batch + 2 <= SPRL_FCACHE && !cfg->no_recycle) ? 1 : 0;
+    long cap = cfg->node_cap > 0 ? cfg->node_cap
+               : P.recycle     ? (long)cfg->num_traversals * 10 + 2048
+                               : (long)cfg->num_traversals * 52 + 1024;
+    if (!single_strip && cap > 65535) cap = 65535;
+    if (cap > 0xFFFFFE) cap = 0xFFFFFE;
     if (cap < cfg->max_batch + 8) cap = cfg->max_batch + 8;
     P.node_cap = (int)cap;
+    if (const char* ab = getenv("SPRL_TEST_ALLOC_BASE"))   // test hook: games start allocating here (crosses the 16-bit boundary early)
+        if (single_strip && atol(ab) > 0 && atol(ab) + cfg->max_batch + 8 < cap) P.alloc_base = (uint32_t)atol(ab);
+    P.wide_idx = cap > 65535 ? 1 : 0;                 // child indices: u16 row, + a u8 row above 65535 nodes
+    P.none_idx = P.wide_idx ? SPRL_NONE24 : SPRL_NONE16;
     P.max_plies = cfg->max_plies > 0 ? cfg->max_plies : e->g.default_max_plies;
     P.max_depth = e->g.max_depth;
     P.planes = e->g.planes;
@@ -350,6 +365,7 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     bool ok = true;
     ok = ok && (P.arenas = (uint8_t*)dev_alloc(e, arenas * (size_t)P.node_cap * (size_t)e->g.node_bytes));
     ok = ok && (P.arena_used = (uint32_t*)dev_alloc(e, arenas * sizeof(uint32_t)));
+    if (P.recycle) ok = ok && (P.reclaim = (uint32_t*)dev_alloc(e, (size_t)P.num_slots * (size_t)P.node_cap * sizeof(uint32_t)));
     ok = ok && (P.ctl = (GameCtl*)dev_alloc(e, (size_t)P.num_slots * sizeof(GameCtl)));
     ok = ok && (P.paths = (uint32_t*)dev_alloc(e, npaths * (size_t)P.max_depth * sizeof(uint32_t)));
     ok = ok && (P.nn_in = (float*)dev_alloc(e, nq * (size_t)e->g.planes * (size_t)e->g.cells * sizeof(float)));

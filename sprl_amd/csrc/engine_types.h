@@ -22,7 +22,9 @@
 #define SPRL_NODE_BYTES 1024
 #define SPRL_ROW 64
 #define SPRL_NONE16 0xFFFFu
+#define SPRL_NONE24 0xFFFFFFu
 #define SPRL_MAXQ 8
+#define SPRL_FCACHE 32      // ready-to-use recycled node ids kept per game (>= max_batch + 2 for recycling to be on)
 
 enum { F_EVAL = 1, F_TERMINAL = 2, F_PASS = 4 };
 enum { ST_IDLE = 0, ST_ACTIVE = 1, ST_ERROR = 2, ST_FRESH = 3 };
@@ -53,7 +55,7 @@ struct NodeHdr {            // 64 bytes at node + 896
 
 struct GameStats {
     unsigned long long traversals, levels, expansions, nn_evals, terminal_hits, gray_hits, dup_hits,
-        nodes_created, compactions, games, plies, max_alloc;
+        nodes_created, compactions, games, plies, max_alloc, nodes_recycled;
     // shader-clock cycles per phase, filled only by the diagnostic build (-DSPRL_PHASE_TIMERS), else 0
     unsigned long long cyc_total, cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio,
         cyc_noise, cyc_max, cyc_lvl_wait, cyc_lvl_pick, cyc_lvl_desc;
@@ -76,6 +78,11 @@ struct GameCtl {
     uint32_t leaf_depth[SPRL_MAXQ];
     uint32_t leaf_sym[SPRL_MAXQ];
     uint32_t leaf_player[SPRL_MAXQ];
+    // node recycling (single-strip kernel): ids of pruned subtrees' roots wait on the game's reclaim stack
+    // (EngineParams::reclaim); a refill pops some, pushes their children and leaves the popped ids here, ready for reuse
+    uint32_t rstack_n;      // height of the reclaim stack
+    uint32_t fc_n;          // valid entries of fcache
+    uint32_t fcache[SPRL_FCACHE];
     GameStats stats;
 };
 
@@ -113,6 +120,11 @@ struct EngineParams {
     int32_t resign_min_ply;
     int32_t go_legal_form;  // wide Go kernel, legal-move computation: 0 by board size, 1 group labels, 2 per-lane flood fill
     int32_t init_q_zero;    // 0 = InitQ::PARENT (workers), 1 = InitQ::ZERO (uct/UCTNode.hpp:24-28,267-273)
+    int32_t wide_idx;       // 1: child indices are 24 bits (u16 row + u8 row in the node's last 64 bytes): node_cap > 65535
+    uint32_t none_idx;      // "no child" in registers: 0xFFFF / 0xFFFFFF
+    uint32_t alloc_base;    // first node index a new game uses (0; a test hook moves it next to the 16-bit boundary)
+    int32_t recycle;        // 1: nodes of pruned siblings are reused (reclaim stack); 0: bump allocation + compaction only
+    uint32_t* reclaim;      // [num_slots][node_cap] reclaim stacks
     // match play (Evaluate.cpp): per-agent options, agent = slot & 1, game = slot >> 1
     int32_t m_use_sym[2], m_eval_kind[2], m_init_q_zero[2];
     uint32_t launch_seq;

@@ -40,14 +40,25 @@ SPRL_DEV float* rowW(uint8_t* n) { return (float*)(n + 256); }
 SPRL_DEV float* rowP(uint8_t* n) { return (float*)(n + 512); }
 SPRL_DEV uint16_t* rowC(uint8_t* n) { return (uint16_t*)(n + 768); }
 SPRL_DEV NodeHdr* hdr_of(uint8_t* n) { return (NodeHdr*)(n + 896); }
+SPRL_DEV uint8_t* rowCH(uint8_t* n) { return n + 960; }     // bits 16..23 of the child indices (arenas above 65535 nodes)
+// this lane's child index: 16 bits, or 24 with the high-byte row when the arena is larger than 65535 nodes (wave-uniform branch)
+SPRL_DEV uint32_t load_child(const EngineParams& P, uint8_t* np) {
+    uint32_t c = rowC(np)[wv::lane()];
+    if (P.wide_idx) c |= (uint32_t)rowCH(np)[wv::lane()] << 16;
+    return c;
+}
+SPRL_DEV void store_child(const EngineParams& P, uint8_t* np, uint32_t c) {
+    rowC(np)[wv::lane()] = (uint16_t)c;
+    if (P.wide_idx) rowCH(np)[wv::lane()] = (uint8_t)(c >> 16);
+}
 // header + this lane's row elements in one batch of loads (the rows of a non-active node are never used)
-SPRL_DEV void load_node(uint8_t* np, NodeHdr& h, float& n, float& w, float& p, uint32_t& ch) {
+SPRL_DEV void load_node(const EngineParams& P, uint8_t* np, NodeHdr& h, float& n, float& w, float& p, uint32_t& ch) {
     const int l = wv::lane();
     h = *hdr_of(np);
     n = rowN(np)[l];
     w = rowW(np)[l];
     p = rowP(np)[l];
-    ch = rowC(np)[l];
+    ch = load_child(P, np);
     wv::sync();
 }
 // wave-uniform copy of a node header; every lane has loaded it before any lane may go on to modify it
@@ -64,6 +75,7 @@ SPRL_DEV NodeHdr load_hdr(uint8_t* n) {
 template <class G>
 struct WaveLds {
     uint32_t path[G::MAX_DEPTH];
+    uint32_t fcache[SPRL_FCACHE];             // recycled node ids ready for reuse (GameCtl::fcache while the slot runs)
     uint64_t hist[G::HIST_CAP][2];
     uint64_t leaf_hist[SPRL_MAXQ][G::HIST][2];
     uint32_t leaf_size[SPRL_MAXQ];
@@ -73,12 +85,13 @@ struct Game {                 // per-wave working state (wave-uniform values)
     Pcg32 rng;
     uint8_t* abase;
     uint32_t arena, root, n_alloc, epoch, root_player, game_id, status;
+    uint32_t rstack_n, fc_n;     // reclaim stack height, ready recycled ids (node recycling)
     float rootN, rootW;
     int ply, traversals, n_leaves;
     // per-launch counter deltas (32-bit: keeps the wave's scalar registers free for the search itself); they are
     // added to the 64-bit totals in GameCtl once, when the slot's state is written back
     uint32_t d_traversals, d_levels, d_expansions, d_nn_evals, d_terminal, d_gray, d_dup, d_created, d_compactions,
-        d_games, d_plies;
+        d_games, d_plies, d_recycled, hi_alloc;
 #if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
     unsigned long long cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise, cyc_lvl_wait,
         cyc_lvl_pick, cyc_lvl_desc;
@@ -96,7 +109,7 @@ SPRL_DEV void raise_error(const EngineParams& P, Game& g, uint32_t code) {
 // node creation (UCTNode::getAddChild -> GameNode::getAddChild -> getNextNodeImpl)
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-SPRL_DEV void write_new_node(uint8_t* np, const Pos& s, int action) {
+SPRL_DEV void write_new_node(const EngineParams& P, uint8_t* np, const Pos& s, int action) {
     NodeHdr* h = hdr_of(np);
     h->p0 = s.p0;
     h->p1 = s.p1;
@@ -106,13 +119,80 @@ SPRL_DEV void write_new_node(uint8_t* np, const Pos& s, int action) {
     h->passN = 0.0f;
     h->passW = 0.0f;
     h->passP = 0.0f;
-    h->passChild = SPRL_NONE16;
+    h->passChild = P.none_idx;
     h->player = s.player;
     h->flags = (uint8_t)((s.terminal ? F_TERMINAL : 0) | (s.pass_legal ? F_PASS : 0));
     h->winner = s.winner;
     h->action = (uint16_t)action;
     h->depth = s.depth;
-    rowC(np)[wv::lane()] = SPRL_NONE16;
+    store_child(P, np, P.none_idx);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// node recycling.  The reference frees the siblings of the move played (UCTNode::pruneChildrenExcept,
+// uct/UCTNode.hpp:356-366; GameNode.hpp:113-122).  Here the old decision node - its edge to the kept child cut - goes on
+// the game's reclaim stack; a refill pops a few ids, pushes their children in their place (one coalesced child-row read
+// each, all requested together) and leaves the popped ids in a small cache the allocator takes from before it bumps the
+// arena.  So a game's arena holds its live subtree plus the garbage not yet reused, not the whole game's nodes.
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+SPRL_DEV uint32_t alloc_node(Game& g, WaveLds<G>* lds) {
+    if (g.fc_n > 0) {
+        g.d_recycled++;
+        return lds->fcache[--g.fc_n];
+    }
+    const uint32_t c = g.n_alloc++;
+    if (g.n_alloc > g.hi_alloc) g.hi_alloc = g.n_alloc;
+    return c;
+}
+
+template <class G>
+SPRL_DEV void reclaim_push(const EngineParams& P, Game& g, int slot, uint32_t node) {
+    if (!P.recycle) return;
+    uint32_t* stack = P.reclaim + (size_t)slot * (size_t)P.node_cap;
+    if (wv::lane() == 0) stack[g.rstack_n] = node;
+    g.rstack_n += 1;
+    wv::wave_fence();
+}
+
+template <class G>
+SPRL_DEV_NOINLINE void reclaim_refill(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds) {
+    const int l = wv::lane();
+    uint32_t* stack = P.reclaim + (size_t)slot * (size_t)P.node_cap;
+    while (g.fc_n < SPRL_FCACHE && g.rstack_n > 0) {
+        // up to 8 ids per pass: their child rows are requested together (one memory round trip per pass)
+        int k = SPRL_FCACHE - (int)g.fc_n;
+        if (k > 8) k = 8;
+        if (k > (int)g.rstack_n) k = (int)g.rstack_n;
+        const uint32_t base = g.rstack_n - (uint32_t)k;
+        const uint32_t mine = l < k ? stack[base + l] : 0u;
+        wv::sync();
+        g.rstack_n = base;
+        uint32_t id[8], ch[8], pc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            id[j] = wv::bcast_u32(mine, j < k ? j : 0);
+            uint8_t* np = node_at(g.abase, id[j]);
+            ch[j] = j < k ? load_child(P, np) : P.none_idx;
+            pc[j] = (G::HAS_PASS && j < k) ? hdr_of(np)->passChild : P.none_idx;
+        }
+        wv::sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j >= k) break;
+            const bool has = ch[j] != P.none_idx;
+            const uint64_t mask = wv::ballot(has);
+            if (has) stack[g.rstack_n + (uint32_t)wv::popc64(mask & wv::lt_mask(l))] = ch[j];
+            g.rstack_n += (uint32_t)wv::popc64(mask);
+            if (G::HAS_PASS && pc[j] != P.none_idx) {
+                if (l == 0) stack[g.rstack_n] = pc[j];
+                g.rstack_n += 1;
+            }
+            if (l == 0) lds->fcache[g.fc_n] = id[j];
+            g.fc_n += 1;
+        }
+        wv::wave_fence();
+    }
 }
 
 template <class G>
@@ -414,7 +494,7 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         NodeHdr h;
         float n, w, p;
         uint32_t ch;
-        load_node(node_at(g.abase, cur), h, n, w, p, ch);
+        load_node(P, node_at(g.abase, cur), h, n, w, p, ch);
         if (G::HIST_CAP > 1 && l == 0) {                   // ancestors: entry ply + d = node at tree depth d
             lds->hist[g.ply][0] = h.p0;
             lds->hist[g.ply][1] = h.p1;
@@ -481,17 +561,17 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
             }
             bool created = false;
             Pos cs;
-            if (c == SPRL_NONE16) {
+            if (c == P.none_idx) {
                 SPRL_TIC(t_cr);
-                c = g.n_alloc++;
+                c = alloc_node<G>(g, lds);
                 created = true;
                 make_child<G>(P, g, lds, pos_of<G>(h), a, g.ply + depth, cs);
-                write_new_node<G>(node_at(g.abase, c), cs, a);
+                write_new_node<G>(P, node_at(g.abase, c), cs, a);
                 SPRL_TOC(g.cyc_create, t_cr);
                 w_a = P.init_q_zero ? 0.0f : h.value;       // InitQ::PARENT / ZERO (UCTNode.hpp:267-273)
                 g.d_created++;
                 if (G::HAS_PASS && a == PASS_A) hp->passChild = c;
-                else if (l == a) rowC(np)[l] = (uint16_t)c;
+                else if (l == a) store_child(P, np, c);
             }
             if (G::HAS_PASS && a == PASS_A) {
                 hp->passN = n_a + 1.0f;
@@ -505,12 +585,12 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
             if (created) {
                 // a freshly created node is empty: header known without reloading it
                 h.p0 = cs.p0; h.p1 = cs.p1; h.legal = cs.legal; h.value = 0.0f; h.exp_epoch = 0;
-                h.passChild = SPRL_NONE16; h.player = cs.player; h.winner = cs.winner;
+                h.passChild = P.none_idx; h.player = cs.player; h.winner = cs.winner;
                 h.action = (uint16_t)a; h.depth = cs.depth;
                 h.flags = (uint8_t)((cs.terminal ? F_TERMINAL : 0) | (cs.pass_legal ? F_PASS : 0));
                 break;
             }
-            load_node(node_at(g.abase, cur), h, n, w, p, ch);
+            load_node(P, node_at(g.abase, cur), h, n, w, p, ch);
 #if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
             g.cyc_lvl_desc += __builtin_amdgcn_s_memtime() - t_l2;
 #endif
@@ -601,10 +681,11 @@ SPRL_DEV_NOINLINE bool compact_arena(const EngineParams& P, Game& g) {
     uint32_t scan = 0, free_ = 1;
     while (scan < free_) {
         uint8_t* np = node_at(to, scan);
-        uint32_t ch = rowC(np)[l];
-        const bool has = ch != SPRL_NONE16;
+        uint32_t ch = load_child(P, np);
+        const bool has = ch != P.none_idx;
         const uint64_t mask = wv::ballot(has);
-        if (has) rowC(np)[l] = (uint16_t)(free_ + (uint32_t)wv::popc64(mask & wv::lt_mask(l)));
+        wv::sync();
+        if (has) store_child(P, np, free_ + (uint32_t)wv::popc64(mask & wv::lt_mask(l)));
         uint32_t k = 0;
         for (uint64_t m = mask; m; m &= m - 1, ++k) {
             uint32_t src = wv::bcast_u32(ch, wv::ctz64(m));
@@ -615,7 +696,7 @@ SPRL_DEV_NOINLINE bool compact_arena(const EngineParams& P, Game& g) {
             NodeHdr* h = hdr_of(np);
             const uint32_t pc = h->passChild;
             wv::sync();
-            if (pc != SPRL_NONE16) {
+            if (pc != P.none_idx) {
                 copy_node(node_at(from, pc), node_at(to, free_));
                 h->passChild = free_;
                 ++free_;
@@ -630,8 +711,22 @@ SPRL_DEV_NOINLINE bool compact_arena(const EngineParams& P, Game& g) {
     g.abase = to;
     g.root = 0;
     g.n_alloc = free_;
+    g.rstack_n = 0;                           // the garbage stayed behind in the arena that was given back
+    g.fc_n = 0;
     g.d_compactions++;
     return true;
+}
+
+// `need` nodes must be available before a search batch (every traversal creates at most one): recycled ids first, then
+// the untouched rest of the arena, then - rarely - a compaction into a spare arena
+template <class G>
+SPRL_DEV bool ensure_nodes(const EngineParams& P, Game& g, int slot, WaveLds<G>* lds, uint32_t need) {
+    if (P.recycle && g.fc_n < need && g.rstack_n > 0) reclaim_refill<G>(P, g, slot, lds);
+    if (g.fc_n + ((uint32_t)P.node_cap - g.n_alloc) >= need) return true;
+    if (!compact_arena<G>(P, g)) return false;
+    if ((uint32_t)P.node_cap - g.n_alloc >= need) return true;
+    raise_error(P, g, ERR_ARENA_FULL);
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -648,9 +743,11 @@ SPRL_DEV void init_game(const EngineParams& P, Game& g, int slot, WaveLds<G>* ld
     rng_seed(g.rng, P.seed, P.stream_base + (int)gid);
     Pos s;
     G::start(s);
-    write_new_node<G>(node_at(g.abase, 0), s, 0);
-    g.root = 0;
-    g.n_alloc = 1;
+    write_new_node<G>(P, node_at(g.abase, P.alloc_base), s, 0);
+    g.root = P.alloc_base;
+    g.n_alloc = P.alloc_base + 1;
+    g.rstack_n = 0;                          // a new game starts on an empty arena: the old tree is dropped whole
+    g.fc_n = 0;
     g.epoch = 1;
     g.root_player = 0;
     g.rootN = 0.0f;                          // UCTTree::m_edgeStatistics slot 0 (UCTTree.hpp:301)
@@ -694,20 +791,25 @@ SPRL_DEV void advance_root(const EngineParams& P, Game& g, int slot, WaveLds<G>*
         n_a = expanded ? h.passN : 0.0f;
         w_a = expanded ? h.passW : 0.0f;
     } else {
-        c = wv::bcast_u32((uint32_t)rowC(np)[l], action);
+        c = wv::bcast_u32(load_child(P, np), action);
         n_a = wv::bcast_f32(rowN(np)[l], action);
         w_a = wv::bcast_f32(rowW(np)[l], action);
         if (!expanded) { n_a = 0.0f; w_a = 0.0f; }
     }
     wv::sync();
-    if (c == SPRL_NONE16) {                   // self-play never gets here (a sampled action has visits > 0)
+    if (c == P.none_idx) {                    // self-play never gets here (a sampled action has visits > 0)
         Pos cs;
         make_child<G>(P, g, lds, pos_of<G>(h), action, g.ply + 1, cs);
-        c = g.n_alloc++;
-        write_new_node<G>(node_at(g.abase, c), cs, action);
+        c = alloc_node<G>(g, lds);
+        write_new_node<G>(P, node_at(g.abase, c), cs, action);
         g.d_created++;
         w_a = (!P.init_q_zero && (h.flags & F_EVAL)) ? h.value : 0.0f;
+    } else if (P.recycle) {                   // pruneChildrenExcept: cut the edge to the kept child, the rest is garbage
+        if (G::HAS_PASS && action == PASS_A) hdr_of(np)->passChild = P.none_idx;
+        else if (l == action) store_child(P, np, P.none_idx);
+        wv::wave_fence();
     }
+    if (P.recycle) reclaim_push<G>(P, g, slot, g.root);
     g.root = c;
     g.rootN = n_a;
     g.rootW = w_a;
@@ -818,6 +920,11 @@ SPRL_DEV void game_load(const EngineParams& P, int slot, GameCtl* ctl, WaveLds<G
     g.traversals = ctl->traversals;
     g.n_leaves = ctl->n_leaves;
     g.root_player = ctl->root_player;
+    g.rstack_n = ctl->rstack_n;
+    g.fc_n = ctl->fc_n;
+    if (wv::lane() < SPRL_FCACHE) lds->fcache[wv::lane()] = ctl->fcache[wv::lane()];
+    g.hi_alloc = g.n_alloc;
+    g.d_recycled = 0;
     g.d_traversals = g.d_levels = g.d_expansions = g.d_nn_evals = g.d_terminal = g.d_gray = g.d_dup = 0;
     g.d_created = g.d_compactions = g.d_games = g.d_plies = 0;
 #if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
@@ -837,8 +944,13 @@ SPRL_DEV void game_load(const EngineParams& P, int slot, GameCtl* ctl, WaveLds<G
     }
 }
 
-SPRL_DEV void game_store(GameCtl* ctl, Game& g, unsigned long long t_all) {
+template <class G>
+SPRL_DEV void game_store(GameCtl* ctl, Game& g, WaveLds<G>* lds, unsigned long long t_all) {
     (void)t_all;
+    ctl->rstack_n = g.rstack_n;
+    ctl->fc_n = g.fc_n;
+    wv::sync();
+    if (wv::lane() < SPRL_FCACHE) ctl->fcache[wv::lane()] = lds->fcache[wv::lane()];
     ctl->status = g.status;
     ctl->rng_state = g.rng.state;
     ctl->rng_inc = g.rng.inc;
@@ -866,7 +978,8 @@ SPRL_DEV void game_store(GameCtl* ctl, Game& g, unsigned long long t_all) {
         t.compactions += g.d_compactions;
         t.games += g.d_games;
         t.plies += g.d_plies;
-        if (g.n_alloc > t.max_alloc) t.max_alloc = g.n_alloc;
+        t.nodes_recycled += g.d_recycled;
+        if (g.hi_alloc > t.max_alloc) t.max_alloc = g.hi_alloc;
 #if defined(SPRL_PHASE_TIMERS) && !defined(SPRL_EMU)
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_all;
         t.cyc_total += dt;
@@ -912,14 +1025,11 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLds<G>* lds) {
             }
         }
         if (idle || g.status != ST_ACTIVE) break;
-        if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) {
-            if (!compact_arena<G>(P, g)) break;
-            if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
-        }
+        if (!ensure_nodes<G>(P, g, slot, lds, (uint32_t)P.max_batch + 1u)) break;
         { SPRL_TIC(t_s); select_batch<G>(P, g, slot, ctl, lds); SPRL_TOC(g.cyc_select, t_s); }
     }
 
-    game_store(ctl, g, t_all);
+    game_store<G>(ctl, g, lds, t_all);
     P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
     if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
 }
@@ -999,15 +1109,12 @@ SPRL_DEV void step_match(const EngineParams& P0, int slot, WaveLds<G>* lds) {
             }
             continue;
         }
-        if (g.n_alloc + (uint32_t)P.max_batch + 2u > (uint32_t)P.node_cap) {
-            if (!compact_arena<G>(P, g)) break;
-            if (g.n_alloc + (uint32_t)P.max_batch + 2u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
-        }
+        if (!ensure_nodes<G>(P, g, slot, lds, (uint32_t)P.max_batch + 2u)) break;
         select_batch<G>(P, g, slot, ctl, lds);
         ++round;
     }
 
-    game_store(ctl, g, 0ull);
+    game_store<G>(ctl, g, lds, 0ull);
     P.leaf_count[slot] = (g.status == ST_ACTIVE && P.eval_kind == EVAL_NETWORK) ? (uint32_t)g.n_leaves : 0u;
     if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
 }

@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("use_symmetry", C.c_int32), ("add_noise", C.c_int32), ("mask_frame", C.c_int32), ("node_cap", C.c_int32),
         ("spare_arenas", C.c_int32), ("max_plies", C.c_int32), ("seed", C.c_uint64), ("stream_base", C.c_int32),
         ("profile", C.c_int32), ("own_stream", C.c_int32), ("resign_threshold", C.c_float),
-        ("resign_min_ply", C.c_int32), ("reserved_", C.c_int32),
+        ("resign_min_ply", C.c_int32), ("no_recycle", C.c_int32),
     ]
 
 
@@ -55,7 +55,7 @@ class Stats(C.Structure):
                           ("hbm_bytes", C.c_int64)] + [(n, C.c_int64) for n in (
         "cyc_total", "cyc_finish", "cyc_move", "cyc_select", "cyc_create", "cyc_backup", "cyc_leafio", "cyc_noise",
         "cyc_max_slot_launch", "cyc_lvl_wait", "cyc_lvl_pick", "cyc_lvl_desc")] + [
-        ("conv_ms", C.c_double), ("conv_launches", C.c_int64), ("conv_boards", C.c_int64)]
+        ("conv_ms", C.c_double), ("conv_launches", C.c_int64), ("conv_boards", C.c_int64), ("nodes_recycled", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -184,6 +184,30 @@ def g7_g9_network():
     save("g7_decode.npz", boards=boards, players=players, masks=masks, policy=pol, value=val)
 
 
+def g9b_baseline_network():
+    """The BASELINE-shape network (BasicGridNetwork(8, 8, 65, 1, 2, 64), scripts/othello_controller.py:297) evaluated by the
+    REFERENCE's own module on CPU in fp32: seed-reproducible weights (netfill.py), 64 Othello-like inputs, outputs."""
+    import torch
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    from src.networks.grid_networks import BasicGridNetwork  # reference definition, this container only
+    sys.path.insert(0, OUT)
+    import netfill
+    seed = 20261004
+    x = netfill.othello_like_inputs(64, seed + 1)
+    out = dict(seed=np.array([seed], np.int64), input=x, gains=np.array([1.0, 2.0]))
+    for gi, gain in enumerate((1.0, 2.0)):       # default-init scale ("random-init net"), and logits of trained-network size
+        ref_net = netfill.fill_state_dict(BasicGridNetwork(8, 8, 65, 1, 2, 64), seed + gi, gain).eval()
+        with torch.no_grad():
+            logits, value = ref_net(torch.from_numpy(x))
+            ld, vd = ref_net.double()(torch.from_numpy(x).double())      # float64 forward of the same weights: the exact answer
+        out[f"logits{gi}"], out[f"value{gi}"] = logits.numpy(), value.numpy()
+        out[f"logits_f64_{gi}"], out[f"value_f64_{gi}"] = ld.numpy(), vd.numpy()
+        out["keys"] = np.array(list(ref_net.state_dict().keys()))
+    save("g9b_baseline_network.npz", **out)
+
+
 MATCH_CASES = [  # game, kind0, kind1, games, traversals, batch, queue, sym0, parentQ0, sym1, parentQ1, seed
     ("othello", 0, 1, 6, 64, 8, 4, 1, 1, 1, 1, 777),
     ("othello", 0, 1, 4, 100, 8, 4, 0, 0, 1, 1, 778),
@@ -203,7 +227,35 @@ def g10_matches():
     save("g10_matches.npz", **out)
 
 
+def g_go9():
+    """Go at 9x9 (BASELINE config 4): the reference compiled with only GO_BOARD_WIDTH = 9 and GO_KOMI = 7.5 changed
+    (oracle/Makefile: ref_go9) - rules play-outs, a search trace and whole games."""
+    assert pyref.lib(variant="go9").ref_go_board_width() == 9 and abs(pyref.lib(variant="go9").ref_go_komi() - 7.5) < 1e-6
+    out = {}
+    for i, seed in enumerate((11, 22, 33, 44)):
+        r = pyref.playout("go9", seed, 1)
+        for k, v in r.items():
+            out[f"playout_{i}_{k}"] = v
+        out[f"playout_{i}_seed"] = np.array([seed], np.int64)
+    st, tr, ch = pyref.search_trace("go9", 0, 3, 200, 16, 8, 0.25, 0.2, SEED, 1)
+    out["trace_stats"], out["trace_trav"], out["trace_chosen"] = st, tr, ch
+    r = pyref.selfplay("go9", 0, 2, 64, 16, 8, 0.25, 0.2, SEED, 1, True)
+    for k in ("boards", "players", "sizes", "dists", "outcomes", "offsets"):
+        out["games_" + k] = r[k]
+    r = pyref.selfplay("go9", 0, 1, 40, 4, 2, 0.25, 0.2, SEED, 7, True, use_sym=0, add_noise=0)
+    for k in ("boards", "players", "sizes", "dists", "outcomes", "offsets"):
+        out["games_nosym_" + k] = r[k]
+    save("g_go9.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g9b":
+        g9b_baseline_network()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "go9":          # only the 9x9 fixtures (needs `make -C oracle ref_go9`)
+        assert pyref.available(variant="go9"), "run `make -C oracle ref_go9` first"
+        g_go9()
+        sys.exit(0)
     assert pyref.available() and pyref.available(True), "run `make -C oracle ref ref_torch` first"
     g6_rng()
     g1_playouts()
@@ -211,4 +263,7 @@ if __name__ == "__main__":
     g4_search()
     g5_games()
     g7_g9_network()
+    g9b_baseline_network()
     g10_matches()
+    if pyref.available(variant="go9"):
+        g_go9()

@@ -34,9 +34,42 @@ def test_othello_heuristic(emu):
 
 
 def test_othello_compaction_with_tiny_arena(emu):
+    """Bump allocation + Cheney compaction alone (node recycling switched off): the fallback path of every game and the
+    allocator of the multi-strip kernel."""
     rec, st = parity.check_case(emu, "othello", 2, concurrent_games=2, num_traversals=40, node_cap=120,
-                                spare_arenas=2)
-    assert st["compactions"] > 0 and st["max_nodes_in_arena"] <= 120
+                                spare_arenas=2, no_recycle=1)
+    assert st["compactions"] > 0 and st["max_nodes_in_arena"] <= 120 and st["nodes_recycled"] == 0
+
+
+def test_node_recycling_keeps_arena_small(emu):
+    """The nodes of pruned siblings are reused (UCTNode::pruneChildrenExcept frees them in the reference): whole games stay
+    bit-identical to the oracle while the arena's high-water mark follows the per-move budget, not the game length - and the
+    tiny arena that forced compactions above now needs none."""
+    rec, st = parity.check_case(emu, "othello", 2, concurrent_games=2, num_traversals=40, node_cap=120, spare_arenas=2)
+    assert st["compactions"] == 0 and st["nodes_recycled"] > 0.5 * st["nodes_created"] and st["max_nodes_in_arena"] <= 120
+    # same games without recycling create the same number of nodes but need several times the space
+    _, _, st0 = parity.run_engine(emu, "othello", 2, concurrent_games=2, num_traversals=40, no_recycle=1, seed=7)
+    assert st0["nodes_created"] == st["nodes_created"] and st0["max_nodes_in_arena"] > 4 * st["max_nodes_in_arena"]
+    for game, kw in (("c4", dict(num_traversals=60, node_cap=200)), ("go", dict(num_traversals=48, node_cap=260))):
+        rec, st = parity.check_case(emu, game, 2, concurrent_games=2, seed=17, **kw)
+        assert st["nodes_recycled"] > 0 and st["compactions"] == 0
+
+
+def test_child_indices_beyond_16_bits(emu, monkeypatch):
+    """a move's tree may exceed 65535 nodes (the reference worker's iteration-0 budget is 131072
+    traversals/move at batch 1, OTHWorker.cpp:17-20).  Arenas above 65535 nodes switch to 24-bit child indices (u16 row +
+    u8 row).  The allocator is started at node 65400 (test hook), so a short game's ids run across the 16-bit boundary -
+    with bump allocation, with recycling and through a compaction."""
+    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65400")
+    rec, st = parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=40, node_cap=70000, no_recycle=1, seed=3)
+    assert st["max_nodes_in_arena"] > 65535 + 500 and st["compactions"] == 0
+    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65520")
+    rec, st = parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=40, node_cap=70000, seed=3)
+    assert st["max_nodes_in_arena"] > 65535 and st["nodes_recycled"] > 0
+    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65400")
+    rec, st = parity.check_case(emu, "go", 1, concurrent_games=1, num_traversals=60, node_cap=65400 + 700, spare_arenas=2,
+                                no_recycle=1, seed=5)
+    assert st["compactions"] > 0
 
 
 def test_othello_no_symmetry_no_noise_batch1(emu):

@@ -33,3 +33,47 @@ def test_portable_games_are_valid_and_deterministic():
     assert (a["dists"].view(np.uint32) == b["dists"].view(np.uint32)).all()
     assert np.allclose(a["dists"].sum(1), 1.0, atol=1e-5)
     assert set(np.unique(a["outcomes"]).tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def _per_game(r, nsym):
+    """Per-game views of an oracle run: (identity-symmetry boards, pdf rows, outcome of ply 0, length, mean root-visit entropy)."""
+    out = []
+    offs = r["offsets"]
+    for g in range(len(offs) - 1):
+        sl = slice(offs[g], offs[g + 1], nsym)
+        pdf = r["dists"][sl]
+        p = np.where(pdf > 0, pdf, 1.0)
+        ent = float(-(pdf * np.log(p)).sum(1).mean())
+        out.append(dict(boards=r["boards"][sl], pdf=pdf, outcome=float(r["outcomes"][offs[g]]), plies=(offs[g + 1] - offs[g]) // nsym,
+                        entropy=ent))
+    return out
+
+
+def test_math_modes_whole_game_divergence_is_rare_and_distribution_preserving():
+    """the device is bit-exact with the oracle in PORTABLE math, the reference with the oracle in LIBM math;
+    the two modes differ by <= 1 ulp in logf/powf/expf, which can flip a gamma rejection test (different RNG consumption) or
+    a CDF comparison.  Measured here on 240 seeded Othello games (200 traversals/move, worker batching): how many whole games
+    are identical, and - for the games that diverge - that length, outcome and root-visit entropy keep their distribution
+    (two-sample KS over ALL games of each mode).  The measured fractions are quoted in DESIGN.md section 2."""
+    from scipy import stats
+    n = 240
+    runs = {}
+    for mode in (po.MATH_LIBM, po.MATH_PORTABLE):
+        cfg = po.make_config(po.GAME_OTHELLO, 200, math_mode=mode)
+        runs[mode] = _per_game(po.selfplay(cfg, n, 2026, 1, True), 8)
+    a, b = runs[po.MATH_LIBM], runs[po.MATH_PORTABLE]
+    same_moves = sum(x["boards"].shape == y["boards"].shape and (x["boards"] == y["boards"]).all() for x, y in zip(a, b))
+    same_bits = sum(x["pdf"].shape == y["pdf"].shape and (x["pdf"].view(np.uint32) == y["pdf"].view(np.uint32)).all() and
+                    (x["boards"] == y["boards"]).all() for x, y in zip(a, b))
+    # pdf values of games that played the same moves: ulp distance
+    worst_ulp = 0
+    for x, y in zip(a, b):
+        if x["boards"].shape == y["boards"].shape and (x["boards"] == y["boards"]).all():
+            d = np.abs(x["pdf"].view(np.int32).astype(np.int64) - y["pdf"].view(np.int32).astype(np.int64)).max()
+            worst_ulp = max(worst_ulp, int(d))
+    ks = {k: stats.ks_2samp([x[k] for x in a], [y[k] for y in b]).pvalue for k in ("plies", "outcome", "entropy")}
+    print(f"math modes, {n} Othello games @200: identical move sequences {same_moves}/{n}, bit-identical records {same_bits}/{n}, "
+          f"worst pdf distance in same-move games {worst_ulp} ulp, KS p-values {ks}")
+    assert same_moves >= 0.5 * n                 # most games do not diverge at all
+    assert worst_ulp <= 64                        # same moves -> pdfs agree to a few ulp (pow(x, 10) amplifies 1 ulp)
+    assert min(ks.values()) > 0.05               # diverged games are distributed like the others

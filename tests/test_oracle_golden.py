@@ -202,6 +202,26 @@ def test_g9_network_contract(golden):
     assert va.shape == (5, 1)
 
 
+def test_g9b_baseline_shape_network_contract(golden):
+    """BASELINE shape (2 blocks x 64 channels): our GridResNet with the seed-reproducible weights of
+    tests/golden/netfill.py == the reference's BasicGridNetwork outputs captured in g9b (CPU fp32, same PyTorch kernels)."""
+    import sys
+    import torch
+    from sprl_amd.network import GridResNet
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import netfill
+    g = golden("g9b_baseline_network.npz")
+    for gi, gain in enumerate(g["gains"]):
+        net = netfill.fill_state_dict(GridResNet(8, 8, 65, 1, 2, 64), int(g["seed"][0]) + gi, float(gain)).eval()
+        assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+        with torch.no_grad():
+            lo, va = net(torch.from_numpy(g["input"]))
+        np.testing.assert_allclose(lo.numpy(), g[f"logits{gi}"], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(va.numpy(), g[f"value{gi}"], atol=1e-5, rtol=0)
+        # how far fp32 itself is from the exact (float64) forward: the yardstick for the GPU tolerance
+        assert np.abs(g[f"logits{gi}"] - g[f"logits_f64_{gi}"]).max() < 5e-6
+
+
 @pytest.mark.skipif(not pyref.available(), reason="prebuilt reference library not present")
 @pytest.mark.parametrize("game,kind,trav,mb,mq,alpha,ngames", [
     ("othello", 0, 200, 8, 4, 0.3, 2), ("othello", 1, 100, 8, 4, 0.3, 2), ("othello", 0, 64, 1, 1, 0.3, 1),
@@ -216,6 +236,56 @@ def test_live_reference_whole_games(game, kind, trav, mb, mq, alpha, ngames):
     for k in ("boards", "players", "sizes", "outcomes"):
         assert (o[k] == r[k]).all()
     assert (bits(o["dists"]) == bits(r["dists"])).all()
+
+
+# ---- Go at 9x9 (BASELINE config 4): fixtures from the reference compiled with ONLY GO_BOARD_WIDTH = 9 / GO_KOMI = 7.5 changed
+# (oracle/Makefile: ref_go9; tests/golden/gen_golden.py: g_go9) -------------------------------------------------------
+def test_go9_playouts_pinned(golden):
+    g = golden("g_go9.npz")
+    for i in range(4):
+        r = po.playout(po.GAME_GO9, int(g[f"playout_{i}_seed"][0]), 1)
+        for k in ("boards", "players", "actions", "terminal"):
+            assert r[k].shape == g[f"playout_{i}_{k}"].shape and (r[k] == g[f"playout_{i}_{k}"]).all(), (i, k)
+        assert (bits(r["masks"]) == bits(g[f"playout_{i}_masks"])).all()
+        assert (r["rewards"] == g[f"playout_{i}_rewards"]).all()          # Tromp-Taylor area + komi 7.5
+        assert r["terminal"][-1] == 1 and r["boards"].shape[1] == 8 * 81 and r["masks"].shape[1] == 82
+
+
+def test_go9_search_trace_pinned(golden):
+    g = golden("g_go9.npz")
+    cfg = po.make_config(po.GAME_GO9, 200, max_batch=16, max_queue=8, dir_alpha=0.2)
+    st, tr, ch = po.search_trace(cfg, 3, SEED, 1)
+    assert (tr == g["trace_trav"]).all() and (ch == g["trace_chosen"]).all()
+    assert (bits(st) == bits(g["trace_stats"])).all()
+
+
+@pytest.mark.parametrize("name,kw,ngames,stream", [
+    ("games", dict(num_traversals=64, max_batch=16, max_queue=8, dir_alpha=0.2), 2, 1),
+    ("games_nosym", dict(num_traversals=40, max_batch=4, max_queue=2, dir_alpha=0.2, use_sym=0, add_noise=0), 1, 7)])
+def test_go9_whole_games_pinned(golden, name, kw, ngames, stream):
+    g = golden("g_go9.npz")
+    r = po.selfplay(po.make_config(po.GAME_GO9, **kw), ngames, SEED, stream, True)
+    assert (r["offsets"] == g[name + "_offsets"]).all()
+    for k in ("boards", "players", "sizes", "outcomes"):
+        assert (r[k] == g[f"{name}_{k}"]).all(), k
+    assert (bits(r["dists"]) == bits(g[name + "_dists"])).all()
+
+
+@pytest.mark.skipif(not pyref.available(variant="go9"), reason="prebuilt 9x9 reference library not present")
+def test_go9_live_reference():
+    """Fresh seeds: oracle at width 9 == the reference compiled at width 9, whole games at the worker's 16/8 batching."""
+    assert pyref.lib(variant="go9").ref_go_board_width() == 9 and pyref.lib(variant="go9").ref_go_komi() == 7.5
+    for trav, ngames, seed in ((160, 2, 99001), (48, 3, 99002)):
+        r = pyref.selfplay("go9", 0, ngames, trav, 16, 8, 0.25, 0.2, seed, 2, True)
+        o = po.selfplay(po.make_config(po.GAME_GO9, trav, max_batch=16, max_queue=8, dir_alpha=0.2), ngames, seed, 2, True)
+        assert (o["offsets"] == r["offsets"]).all()
+        for k in ("boards", "players", "sizes", "outcomes"):
+            assert (o[k] == r[k]).all(), k
+        assert (bits(o["dists"]) == bits(r["dists"])).all()
+    for seed in (5, 6, 7):
+        r, o = pyref.playout("go9", seed, 3), po.playout(po.GAME_GO9, seed, 3)
+        assert all((o[k] == r[k]).all() for k in ("boards", "players", "actions", "terminal", "rewards"))
+        assert (bits(o["masks"]) == bits(r["masks"])).all()
 
 
 def _match_cfg(game, kind, trav, mb, mq, sym, parent_q):

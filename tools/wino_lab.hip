@@ -107,11 +107,9 @@ int main(int argc, char** argv) {
 
     std::vector<Variant> vs = {
         { "v2 product (U36 from L2)", launch_v2, 0 },
-        { "v4 G9 on-the-fly", launch_v4<0>, 1 },
-        { "v4 G9 valu-cross", launch_v4<1>, 1 },
-        { "v4 G9 persistent", launch_v4<2>, 1 },
-        { "v4 G9 grouped-sched", launch_v4<4>, 1 },
-        { "v4 G9 grouped-sched persistent", launch_v4<6>, 1 },
+        { "v4 G9 + b128 V layout", launch_v4<8>, 1 },
+        { "v4 G9 + b128 + scaled transforms", launch_v4<8 + 16>, 1 },
+        { "v4 G9 + scaled transforms (b32 V)", launch_v4<16>, 1 },
     };
 
     // float64 reference for boards 0..3 and the last board (direct 3x3 convolution, padding 1, + scale/shift + residual + ReLU)
@@ -154,6 +152,7 @@ int main(int argc, char** argv) {
         double err = 0.0;
         long nan_ref = 0, nan_all = 0, bad_all = 0;
         int shown = 0;
+        long hist[8][4] = {};
         for (int cb = 0; cb < 5; ++cb)
             for (int k = 0; k < 64; ++k)
                 for (int cell = 0; cell < 64; ++cell) {
@@ -174,11 +173,48 @@ int main(int argc, char** argv) {
                 if (std::isnan(d)) ++nan_all;
                 else {
                     if (d > dv2) dv2 = d;
-                    if (d > 1e-3) ++bad_all;
+                    if (d > 1e-3) {
+                        ++bad_all;
+                        // layout W: [n][g][i][cs][tile][j]
+                        const size_t w = i & 4095;
+                        ++hist[0][(i >> 12) & 3]; ++hist[1][w & 3]; ++hist[2][(w >> 2) & 3]; ++hist[3][(w >> 4) & 3];
+                        ++hist[4][(w >> 6) & 3]; ++hist[5][(w >> 8) & 3]; ++hist[6][(w >> 10) & 3];
+                        ++hist[7][((i >> 12) / 4) % 4];
+                    }
                 }
             }
+        if (bad_all) {
+            const char* names[8] = { "board%4", "j", "tile", "cs", "i", "g&3 (=r)", "g>>2 (=kb)", "group%4" };
+            for (int h = 0; h < 8; ++h) printf("      mismatches by %-10s %ld %ld %ld %ld\n", names[h], hist[h][0], hist[h][1], hist[h][2], hist[h][3]);
+        }
         printf("  check %-34s max|err| vs f64 direct (5 boards) %.3e (NaN %ld)   vs v2 (all boards): max|diff| %.3e, >1e-3: %ld, NaN: %ld\n",
                vs[vi].name, err, nan_ref, dv2, bad_all, nan_all);
+    }
+
+    {   // where a workgroup's time goes: shader-clock stamps of wave 0 (diagnostic build of the same kernel)
+        const int ngroups = (B + 3) / 4;
+        unsigned long long* st;
+        hipMalloc(&st, (size_t)ngroups * 16 * 8);
+        hipMemset(st, 0, (size_t)ngroups * 16 * 8);
+        for (int rep = 0; rep < 3; ++rep) sprl_wino_conv64_v4_launch<32>(x, g9, sc, sh, r, y, B, 1, nullptr, nullptr, (float*)st);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> hs((size_t)ngroups * 16);
+        hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[11] = { "prologue", "phase0", "phase1", "phase2", "phase3", "phase4", "phase5", "phase6", "phase7", "output", "total" };
+        printf("  stamps (shader cycles per workgroup, wave 0; %d workgroups): median / p10 / p90\n", ngroups);
+        for (int k = 0; k < 11; ++k) {
+            std::vector<double> v;
+            for (int gi = 0; gi < ngroups; ++gi) {
+                const unsigned long long* q = &hs[(size_t)gi * 16];
+                v.push_back(k < 10 ? (double)(q[k + 1] - q[k]) : (double)(q[10] - q[0]));
+            }
+            std::sort(v.begin(), v.end());
+            printf("    %-9s %9.0f %9.0f %9.0f\n", names[k], v[v.size() / 2], v[v.size() / 10], v[v.size() * 9 / 10]);
+        }
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (int gi = 0; gi < ngroups; ++gi) { tmin = std::min(tmin, hs[(size_t)gi * 16]); tmax = std::max(tmax, hs[(size_t)gi * 16 + 10]); }
+        printf("    first start -> last end: %.0f cycles\n", (double)(tmax - tmin));
+        hipFree(st);
     }
 
     hipEvent_t e0, e1;
