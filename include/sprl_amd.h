@@ -61,7 +61,7 @@ typedef struct sprl_config {
     int32_t mask_frame;        /* SPRL_MASK_* */
     int32_t node_cap;          /* nodes per game arena (1 KiB each; Go 9x9 2 KiB, 19x19 5.5 KiB); 0 = default.  Othello / Connect Four /
                                   Go 7x7: < 2^24 (child indices widen from 16 to 24 bits above 65535), nodes of pruned siblings are
-                                  reused, default 10 x num_traversals + 2048.  Boards wider than 8x8: <= 65535 */
+                                  reused, default 4 x num_traversals + 1024.  Boards wider than 8x8: <= 65535 */
     int32_t spare_arenas;      /* arenas kept free for compaction; 0 = default */
     int32_t max_plies;         /* record capacity per game; 0 = default */
     uint64_t seed;             /* game g uses Random(seed, stream_base + g) (utils/random.hpp:92-103); a later run on the same
@@ -142,6 +142,22 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games);
 int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_t* active_slots);
 int sprl_engine_collect(sprl_engine* e, sprl_records* out);
 void sprl_records_free(sprl_records* r);
+
+/* Finished-game records WITHOUT a host copy (after sprl_engine_step has reported every game done, instead of / before
+ * sprl_engine_collect).  All pointers are DEVICE memory owned by the caller.
+ *   records_info   total plies, samples (= plies x nsym when the engine symmetrises) and the size of the packed form;
+ *   pack_records   the compact wire format of the multi-GPU gather - head int64[12], offsets int32[games+1], winners int8[games],
+ *                  stones uint64[plies][words] x 2, movers uint8[plies], pdfs float32[plies][actions], sections 16-byte aligned
+ *                  (sprl_amd/distributed.py) - so that ranks hand RCCL a device buffer;
+ *   expand_records the reference worker's samples (selfplay/SelfPlay.hpp:86-92,127-133,151-189 + the plane encoding of
+ *                  selfplay/GridWorker.hpp:146-171): states float32[N][2H+1][R][C], distributions float32[N][A], outcomes
+ *                  float32[N], written straight into e.g. the trainer's replay window;
+ *   finish         ends the run (like collect, without producing host records). */
+int sprl_engine_records_info(sprl_engine* e, int64_t* total_plies, int64_t* num_samples, int64_t* packed_bytes);
+int sprl_engine_pack_records(sprl_engine* e, void* dst_device, int64_t capacity_bytes);
+int sprl_engine_expand_records(sprl_engine* e, float* states_device, float* distributions_device, float* outcomes_device,
+                               int64_t capacity_samples);
+int sprl_engine_finish(sprl_engine* e);
 
 typedef struct sprl_stats {
     int64_t games, plies, traversals, levels, expansions, nn_evals, terminal_hits, gray_hits, dup_hits,

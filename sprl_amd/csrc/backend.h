@@ -10,6 +10,9 @@
 
 #include "engine_types.h"
 
+struct RecPacked;       // records_kernel.h
+struct RecExpanded;
+
 namespace be {
 bool available(std::string* why);
 int init(int device, std::string* err);
@@ -32,6 +35,10 @@ int launch_match(int game, const EngineParams& P);
 // leaf_count -> leaf_offset (exclusive scan, slot order) + counters->leaf_total, then gather the queued leaves'
 // planes from the sparse staging into the dense network batch
 int launch_compact(const EngineParams& P, int floats_per_leaf);
+// finished-game records on the device (records_kernel.h): offsets scan, wire-format packing, training-sample expansion
+int launch_records_scan(const EngineParams& P);
+int launch_records_pack(int game, const EngineParams& P, const RecPacked& out, int use_sym);
+int launch_records_expand(int game, const EngineParams& P, const RecExpanded& out);
 // event pairs on the null stream (profile mode); returns milliseconds between the two marks
 void* mark();
 double elapsed_ms(void* a, void* b);   // synchronises on b

@@ -4,6 +4,7 @@
 #include <string>
 
 #include "backend.h"
+#include "records_kernel.h"
 #include "step_kernel.h"
 #include "step_kernel_wide.h"
 
@@ -84,6 +85,41 @@ __global__ void __launch_bounds__(64) leaf_gather_kernel(EngineParams P, int flo
         for (int i = vec * 4 + (int)threadIdx.x; i < floats_per_leaf; i += 64)
             P.nn_dense[(size_t)(off + q) * floats_per_leaf + i] = P.nn_in[((size_t)slot * P.max_queue + q) * floats_per_leaf + i];
     }
+}
+
+// Exclusive prefix sum of the per-game ply counts (one 1024-thread workgroup, as leaf_scan_kernel): rec_offsets[g],
+// rec_offsets[num_games] = total plies of the run.
+__global__ void __launch_bounds__(1024) records_scan_kernel(const int32_t* nplies, int32_t* offsets, int n) {
+    __shared__ int32_t part[1024];
+    const int t = (int)threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk, hi = min(n, lo + chunk);
+    int32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += nplies[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int32_t run = part[t] - sum;
+    for (int i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += nplies[i];
+    }
+    if (t == 1023) offsets[n] = part[1023];
+}
+
+template <class G>
+__global__ void __launch_bounds__(64) records_pack_kernel(EngineParams P, RecPacked out, int use_sym) {
+    rec_pack_game<G>(P, out, (int)blockIdx.x, (int)threadIdx.x, use_sym);
+}
+
+template <class G>
+__global__ void __launch_bounds__(64) records_expand_kernel(EngineParams P, RecExpanded out) {
+    rec_expand_game<G>(P, out, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 }  // namespace
@@ -186,6 +222,38 @@ int launch_compact(const EngineParams& P, int floats_per_leaf) {
     hipLaunchKernelGGL(leaf_scan_kernel, dim3(1), dim3(1024), 0, g_stream, P.leaf_count, P.leaf_offset, P.counters, P.num_slots);
     hipLaunchKernelGGL(leaf_gather_kernel, dim3((unsigned)P.num_slots), dim3(64), 0, g_stream, P, floats_per_leaf);
     return ok(hipGetLastError(), "leaf compaction launch") ? 0 : -1;
+}
+
+int launch_records_scan(const EngineParams& P) {
+    hipLaunchKernelGGL(records_scan_kernel, dim3(1), dim3(1024), 0, g_stream, P.rec_nplies, P.rec_offsets, P.num_games);
+    return ok(hipGetLastError(), "records scan launch") ? 0 : -1;
+}
+
+#define SPRL_FOR_GAME(game, CALL)                                           \
+    switch (game) {                                                         \
+    case SPRL_GAME_OTHELLO: CALL(Othello); break;                           \
+    case SPRL_GAME_CONNECT_FOUR: CALL(ConnectFour); break;                  \
+    case SPRL_GAME_GO7: CALL(Go7); break;                                   \
+    case SPRL_GAME_GO9: CALL(GoN<9>); break;                                \
+    case SPRL_GAME_GO19: CALL(GoN<19>); break;                              \
+    case SPRL_GAME_GO7W: CALL(GoN<7>); break;                               \
+    default: g_err = "unknown game"; return -1;                             \
+    }
+
+int launch_records_pack(int game, const EngineParams& P, const RecPacked& out, int use_sym) {
+    const dim3 grid((unsigned)P.num_games), block(64);
+#define SPRL_CALL(G) hipLaunchKernelGGL(records_pack_kernel<G>, grid, block, 0, g_stream, P, out, use_sym)
+    SPRL_FOR_GAME(game, SPRL_CALL)
+#undef SPRL_CALL
+    return ok(hipGetLastError(), "records pack launch") ? 0 : -1;
+}
+
+int launch_records_expand(int game, const EngineParams& P, const RecExpanded& out) {
+    const dim3 grid((unsigned)P.num_games), block(64);
+#define SPRL_CALL(G) hipLaunchKernelGGL(records_expand_kernel<G>, grid, block, 0, g_stream, P, out)
+    SPRL_FOR_GAME(game, SPRL_CALL)
+#undef SPRL_CALL
+    return ok(hipGetLastError(), "records expand launch") ? 0 : -1;
 }
 
 void* mark() {

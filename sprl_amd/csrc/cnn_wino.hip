@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (y && !TAIL) ? act_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wts, 0, (unsigned)G9_FLOATS * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wts, 0, (FLAGS & 8192) ? 36u * 4096u * 4u : (FLAGS & 4096) ? 24u * 4096u * 4u : (unsigned)G9_FLOATS * 4u, 0x00020000);
     const int wlane16 = lane * 16, wlane4 = lane * 4;
     const int ooff = ((tl >> 2) * 4096 + c_sub * 16 + (tl & 3) * 4) * 4;   // bytes: this lane's board, channel slot and tile
     const int tile = tl & 3, ty = tile >> 1, tx = tile & 1;
@@ -744,7 +744,20 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
         // ---- A operand: the 3x3 filters of K step s for this lane's (out channel, in channel), two register sets ----
         f4 gq0[2], gq1[2];
         float gq2[2];
+        f4 ring[(FLAGS & 8192) ? 9 : (FLAGS & 4096) ? 6 : 1];   // FLAGS 4096: T'[6 rows][3] (+pad) / 8192: U'[36] of the current K step
+        auto ring_load = [&](int s, int i) {
+            // T18: T4[s][kb][row][lane][4] (6 KB per wave and step); U36: U4[quad][s][kb][lane][4] (9 KB per wave and step)
+            const int off = (FLAGS & 8192) ? (i * 16 + s) * 4096 + kb * 1024 : (s * 4 + kb) * 6144 + i * 1024;
+            ring[((FLAGS & 8192) || (FLAGS & 4096)) ? i : 0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane16, off, 0));
+        };
         auto wload = [&](int s) {
+            if (FLAGS & (4096 | 8192)) {
+                if (s == 0) {
+#pragma unroll
+                    for (int i = 0; i < ((FLAGS & 8192) ? 9 : 6); ++i) ring_load(0, i);
+                }
+                return;
+            }
             gq0[s & 1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane16, wbase + s * 8192, 0));
             gq1[s & 1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane16, wbase + s * 8192 + 1024, 0));
             gq2[s & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wlane4, (wbase >> 3) + 16 * 8192 + s * 1024, 0));
@@ -757,6 +770,54 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
         // one K step = one group of 4 input channels: 36 MFMAs; `chunk` >= 0: request that activation chunk behind the filters
         auto kstep = [&](const float* vg, int s, int chunk) {
             __builtin_amdgcn_sched_barrier(0);
+            if (FLAGS & 8192) {                           // U' streamed from L2 (no filter arithmetic): a quad is reloaded behind its MFMAs
+                if (chunk >= 0) gload_to(chunk, pre);
+                if (FLAGS & 8) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 9; ++q4) bq[q4] = *(const f4*)(vg + q4 * 256 + lane * 4);
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 9; ++q4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mma1(vg, q4 * 4 + e, ring[(FLAGS & 8192) ? q4 : 0][e]);
+                    if (s + 1 < 16) ring_load(s + 1, q4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
+            if (FLAGS & 4096) {                           // T' = G' g streamed (18 floats): 6 operations per row of U', one row ahead
+                if (chunk >= 0) gload_to(chunk, pre);
+                if (FLAGS & 8) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 9; ++q4) bq[q4] = *(const f4*)(vg + q4 * 256 + lane * 4);
+                }
+                auto f6 = [](float x0, float x1, float x2, float (&yv)[6]) {
+                    const float t = x0 + x2, p = x0 + 4.0f * x2;
+                    yv[0] = x0;
+                    yv[1] = t + x1;
+                    yv[2] = t - x1;
+                    yv[3] = p + 2.0f * x1;
+                    yv[4] = p - 2.0f * x1;
+                    yv[5] = x2;
+                };
+                float ua[6], ub[6];
+                f6(ring[(FLAGS & 4096) ? 0 : 0][0], ring[0][1], ring[0][2], ua);
+                if (s + 1 < 16) ring_load(s + 1, 0);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    float (&cur)[6] = (a & 1) ? ub : ua;
+                    float (&nxt)[6] = (a & 1) ? ua : ub;
+                    if (a + 1 < 6) {
+                        const int r1 = (FLAGS & 4096) ? a + 1 : 0;
+                        f6(ring[r1][0], ring[r1][1], ring[r1][2], nxt);
+                        if (s + 1 < 16) ring_load(s + 1, a + 1);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) mma1(vg, a * 6 + b, cur[b]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             if (s + 1 < 16 && !(FLAGS & 128)) wload(s + 1);
             if (chunk >= 0 && !(FLAGS & 1024)) gload_to(chunk, pre);
             __builtin_amdgcn_sched_barrier(0);            // the loads stay here, a whole K step ahead of their first use
@@ -780,6 +841,45 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_v4_kernel(const float* _
                     yv[4] = p - 2.0f * x1;
                     yv[5] = x2;
                 };
+                if (FLAGS & 2048) {
+                    // software pipeline: the six U values of row r+1 are computed BEFORE the six MFMAs of row r are issued, so no
+                    // MFMA reads a register a VALU instruction has just written (tools/mfma_valu_probe: +10..15 cycles per MFMA)
+                    float ua[6], ub[6], t1[3], t2[3], t3[3], t4[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float t = g[0][j] + g[2][j], p = g[0][j] + 4.0f * g[2][j];
+                        t1[j] = t + g[1][j];
+                        t2[j] = t - g[1][j];
+                        t3[j] = p + 2.0f * g[1][j];
+                        t4[j] = p - 2.0f * g[1][j];
+                    }
+                    f6(g[0][0], g[0][1], g[0][2], ua);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f6(t1[0], t1[1], t1[2], ub);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) mma1(vg, b, ua[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f6(t2[0], t2[1], t2[2], ua);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) mma1(vg, 6 + b, ub[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f6(t3[0], t3[1], t3[2], ub);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) mma1(vg, 12 + b, ua[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f6(t4[0], t4[1], t4[2], ua);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) mma1(vg, 18 + b, ub[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f6(g[2][0], g[2][1], g[2][2], ub);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) mma1(vg, 24 + b, ua[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) mma1(vg, 30 + b, ub[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    return;
+                }
                 f6(g[0][0], g[0][1], g[0][2], uu);                               // row 0 of T' = g[0][.]
 #pragma unroll
                 for (int b = 0; b < 6; ++b) mma1(vg, b, uu[b]);

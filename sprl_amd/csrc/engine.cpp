@@ -20,6 +20,7 @@
 #include "engine_types.h"
 #include "games.h"
 #include "games_wide.h"
+#include "records_kernel.h"
 
 namespace {
 
@@ -117,6 +118,7 @@ struct sprl_engine {
     bool dev_batch = false;     // the evaluator takes the batch size from device memory: rounds are enqueued without a host sync
     unsigned long long last_leaf_rows = 0;
     double seconds = 0.0, kernel_ms = 0.0, nn_ms = 0.0;
+    int64_t rec_total = -1;     // total plies of the finished run once the device-side offsets scan has run, else -1
     std::vector<void*> marks;  // k0,k1,(n0,n1) per round, resolved lazily
     std::vector<int> mark_kind;
 };
@@ -339,12 +341,13 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.num_slots = cfg->concurrent_games;
     P.num_spare = cfg->spare_arenas > 0 ? cfg->spare_arenas : (cfg->concurrent_games / 64 > 8 ? cfg->concurrent_games / 64 : 8);
     // Node recycling (single-strip kernel): an arena holds the live subtree + the garbage not yet reused, so its size follows
-    // the per-move budget, not the game length: 10 x traversals + 2048 nodes is ~2x the high-water mark measured over whole
-    // Othello / Connect Four / Go 7x7 games; compaction into a spare arena remains the fallback.
+    // the per-move budget, not the game length.  High-water marks measured over whole games: Othello @800 1 291 nodes,
+    // Connect Four @512 673, Go 7x7 @400 487 - 4 x traversals + 1024 leaves a 3-5x margin; compaction
+    // into a spare arena remains the fallback.
     // Boards wider than 8x8 (multi-strip kernel): bump allocation + compaction, 16-bit child indices.
     P.recycle = (single_strip && cfg->max_batch + 2 <= SPRL_FCACHE && !cfg->no_recycle) ? 1 : 0;
     long cap = cfg->node_cap > 0 ? cfg->node_cap
-               : P.recycle     ? (long)cfg->num_traversals * 10 + 2048
+               : P.recycle     ? (long)cfg->num_traversals * 4 + 1024
                                : (long)cfg->num_traversals * 52 + 1024;
     if (!single_strip && cap > 65535) cap = 65535;
     if (cap > 0xFFFFFE) cap = 0xFFFFFE;
@@ -485,9 +488,11 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
         ok = ok && (P.rec_movers = (uint8_t*)dev_alloc(e, np));
         ok = ok && (P.rec_pdf = (float*)dev_alloc(e, np * (size_t)e->g.A * sizeof(float)));
         ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
+        ok = ok && (P.rec_offsets = (int32_t*)dev_alloc(e, ((size_t)num_games + 1) * sizeof(int32_t)));
         ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
         if (!ok) return fail(SPRL_E_DEVICE, std::string("record allocation failed (") + be::last_error() + ")");
     }
+    e->rec_total = -1;
     if (e->games_begun > 0) {                    // keep the search counters of the run that is being replaced
         std::vector<GameCtl> old((size_t)P.num_slots);
         if (be::sync() != 0 || be::d2h(old.data(), P.ctl, old.size() * sizeof(GameCtl)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
@@ -685,6 +690,98 @@ int sprl_engine_collect(sprl_engine* e, sprl_records* out) {
     out->pdfs = o->pdfs.data();
     out->winners = o->winners.data();
     out->owner_ = o;
+    e->running = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finished-game records on the device (records_kernel.h)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+int64_t align16(int64_t v) { return (v + 15) & ~(int64_t)15; }
+struct PackedLayout { int64_t offsets, winners, stones0, stones1, movers, pdfs, total; };
+// byte offsets of the sections of a packed shard (the same rule as sprl_amd/distributed.py: section_offsets)
+PackedLayout packed_layout(int64_t games, int64_t plies, int64_t actions, int64_t words) {
+    PackedLayout L;
+    int64_t p = 12 * 8;
+    L.offsets = p; p = align16(p + 4 * (games + 1));
+    L.winners = p; p = align16(p + games);
+    L.stones0 = p; p = align16(p + 8 * words * plies);
+    L.stones1 = p; p = align16(p + 8 * words * plies);
+    L.movers = p; p = align16(p + plies);
+    L.pdfs = p; p = align16(p + 4 * plies * actions);
+    L.total = p;
+    return L;
+}
+int records_ready(sprl_engine* e) {
+    if (!e->running) return fail(SPRL_E_STATE, "no run in progress");
+    if (e->rec_total >= 0) return 0;
+    Counters c;
+    if (be::sync() != 0 || be::d2h(&c, e->P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+    if (c.games_done < (uint32_t)e->num_games) return fail(SPRL_E_STATE, "records requested before every game has finished");
+    int32_t total = 0;
+    if (be::launch_records_scan(e->P) != 0 || be::sync() != 0 ||
+        be::d2h(&total, e->P.rec_offsets + e->num_games, sizeof(total)) != 0)
+        return fail(SPRL_E_DEVICE, be::last_error());
+    e->rec_total = total;
+    return 0;
+}
+}  // namespace
+
+int sprl_engine_records_info(sprl_engine* e, int64_t* total_plies, int64_t* num_samples, int64_t* packed_bytes) {
+    if (!e) return fail(SPRL_E_CONFIG, "null engine");
+    be::bind(e->cfg.device, e->stream);
+    int rc = records_ready(e);
+    if (rc) return rc;
+    if (total_plies) *total_plies = e->rec_total;
+    if (num_samples) *num_samples = e->rec_total * (e->cfg.use_symmetry ? e->g.nsym : 1);
+    if (packed_bytes) *packed_bytes = packed_layout(e->num_games, e->rec_total, e->g.A, e->g.words).total;
+    return 0;
+}
+
+int sprl_engine_pack_records(sprl_engine* e, void* dst_device, int64_t capacity_bytes) {
+    if (!e || !dst_device) return fail(SPRL_E_CONFIG, "null argument");
+    be::bind(e->cfg.device, e->stream);
+    int rc = records_ready(e);
+    if (rc) return rc;
+    const PackedLayout L = packed_layout(e->num_games, e->rec_total, e->g.A, e->g.words);
+    if (capacity_bytes < L.total) return fail(SPRL_E_CONFIG, "destination too small for the packed records (sprl_engine_records_info)");
+    if ((uintptr_t)dst_device & 15u) return fail(SPRL_E_CONFIG, "destination must be 16-byte aligned");
+    uint8_t* d = (uint8_t*)dst_device;
+    if (be::dmemset(d, 0, (size_t)L.total) != 0) return fail(SPRL_E_DEVICE, be::last_error());     // padding bytes are zero
+    RecPacked o;
+    o.head = (int64_t*)d;
+    o.offsets = (int32_t*)(d + L.offsets);
+    o.winners = (int8_t*)(d + L.winners);
+    o.stones0 = (uint64_t*)(d + L.stones0);
+    o.stones1 = (uint64_t*)(d + L.stones1);
+    o.movers = d + L.movers;
+    o.pdfs = (float*)(d + L.pdfs);
+    if (be::launch_records_pack(e->cfg.game, e->P, o, e->cfg.use_symmetry ? 1 : 0) != 0 || be::sync() != 0)
+        return fail(SPRL_E_DEVICE, be::last_error());
+    return 0;
+}
+
+int sprl_engine_expand_records(sprl_engine* e, float* states_device, float* distributions_device, float* outcomes_device,
+                               int64_t capacity_samples) {
+    if (!e || !states_device || !distributions_device || !outcomes_device) return fail(SPRL_E_CONFIG, "null argument");
+    be::bind(e->cfg.device, e->stream);
+    int rc = records_ready(e);
+    if (rc) return rc;
+    const int ns = e->cfg.use_symmetry ? e->g.nsym : 1;
+    if (capacity_samples < e->rec_total * ns) return fail(SPRL_E_CONFIG, "destination too small for the expanded samples");
+    RecExpanded o;
+    o.states = states_device;
+    o.dists = distributions_device;
+    o.outcomes = outcomes_device;
+    o.nsym = ns;
+    if (be::launch_records_expand(e->cfg.game, e->P, o) != 0 || be::sync() != 0) return fail(SPRL_E_DEVICE, be::last_error());
+    return 0;
+}
+
+int sprl_engine_finish(sprl_engine* e) {
+    if (!e) return fail(SPRL_E_CONFIG, "null engine");
+    if (!e->running) return fail(SPRL_E_STATE, "no run in progress");
     e->running = false;
     return 0;
 }

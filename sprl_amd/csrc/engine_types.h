@@ -145,6 +145,7 @@ struct EngineParams {
     uint8_t* rec_movers;
     float* rec_pdf;
     int32_t* rec_nplies;
+    int32_t* rec_offsets;   // [num_games + 1] exclusive prefix sum of rec_nplies (records_kernel.h), filled by the records scan
     int8_t* rec_winner;
     Counters* counters;
 };

@@ -112,6 +112,10 @@ def load_library(path=None):
     L.sprl_engine_begin.argtypes = [C.c_void_p, C.c_int32]
     L.sprl_engine_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprl_engine_collect.argtypes = [C.c_void_p, C.POINTER(Records)]
+    L.sprl_engine_records_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.sprl_engine_pack_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.sprl_engine_expand_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.sprl_engine_finish.argtypes = [C.c_void_p]
     L.sprl_records_free.argtypes = [C.POINTER(Records)]
     L.sprl_records_free.restype = None
     L.sprl_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -250,6 +254,24 @@ class Engine:
         rec = Records()
         self._check(self._lib.sprl_engine_collect(self._h, C.byref(rec)))
         return SelfPlayRecords(self._lib, rec)
+
+    def records_info(self):
+        """(total plies, samples, packed bytes) of the finished run, from the device (no record copy)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.sprl_engine_records_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def pack_records_into(self, dst_ptr, capacity_bytes):
+        """Write the run's compact records in the gather's wire format into DEVICE memory at `dst_ptr` (16-byte aligned)."""
+        self._check(self._lib.sprl_engine_pack_records(self._h, C.c_void_p(dst_ptr), capacity_bytes))
+
+    def expand_records_into(self, states_ptr, dists_ptr, outcomes_ptr, capacity_samples):
+        """Write the reference's training samples (planes, distributions, outcomes) into DEVICE buffers."""
+        self._check(self._lib.sprl_engine_expand_records(self._h, C.c_void_p(states_ptr), C.c_void_p(dists_ptr),
+                                                         C.c_void_p(outcomes_ptr), capacity_samples))
+
+    def finish(self):
+        self._check(self._lib.sprl_engine_finish(self._h))
 
     def stats(self):
         st = Stats()

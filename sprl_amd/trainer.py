@@ -81,49 +81,75 @@ def learning_rate_for(cfg: TrainerConfig, iteration: int) -> float:
     return lr
 
 
-def _evaluate(net, tensors, idx, batch_size):
+def _evaluate(net, tensors, batches):
+    """Mean over validation batches of the two weighted losses; returns (policy sum, value sum, batch count)."""
     s, d, o, t = tensors
     pol = val = 0.0
     n = 0
     with torch.no_grad():
-        for k in range(0, idx.numel(), batch_size):
-            b = idx[k:k + batch_size]
+        for b in batches:
             lo, va = net(s[b])
             p, v = weighted_losses(lo, va, d[b], o[b], t[b])
             pol += p.item()
             val += v.item()
             n += 1
-    return pol / max(1, n), val / max(1, n)
+    return pol, val, n
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
 def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Optional[torch.Generator] = None,
-                  ddp: bool = False, log=None):
-    """One controller iteration of training.  Returns (best_state_dict, history); `net` itself keeps training weights
-    (the reference traces the best-validation snapshot but carries the live network into the next iteration)."""
+                  ddp: bool = False, log=None, index_plan=None):
+    """One controller iteration of training (scripts/othello_controller.py:128-241).  Returns (best_state_dict, history);
+    `net` itself keeps training weights (the reference traces the best-validation snapshot but carries the live network into
+    the next iteration).
+
+    index_plan: optional callable epoch -> (train_batches, val_batches), lists of index tensors; replaces the random 90/10
+    split and the per-epoch shuffles (tests replay the batches the reference controller drew, tests/golden/g_trainer.npz).
+
+    ddp=True with torch.distributed initialised (backend "nccl" = RCCL): every rank trains on the samples of its own game
+    shard with gradient all-reduce.  Shards differ in size (game lengths vary), so the number of optimiser steps per epoch is
+    agreed first (MAX over ranks; shorter shards wrap around) and the validation sums are all-reduced before the best-epoch
+    and early-stop decisions: every rank takes the same decisions and exports the same weights."""
     s, d, o, t = tensors
     device = s.device
     net.to(device)
     n = s.shape[0]
-    perm = torch.randperm(n, device=device, generator=generator)
-    n_train = int((1.0 - cfg.val_fraction) * n)                                  # :135-138
-    train_idx, val_idx = perm[:n_train], perm[n_train:]
+    dist = _dist() if ddp else None
+    if index_plan is None:
+        perm = torch.randperm(n, device=device, generator=generator)
+        n_train = int((1.0 - cfg.val_fraction) * n)                              # :135-138
+        train_idx, val_idx = perm[:n_train], perm[n_train:]
+        steps = (train_idx.numel() + cfg.batch_size - 1) // cfg.batch_size
+        if dist is not None:                                                     # same number of all-reduces on every rank
+            st = torch.tensor([steps], device=device)
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            steps = int(st.item())
     model = net
-    if ddp:
-        import torch.distributed as dist
+    if dist is not None:
         from torch.nn.parallel import DistributedDataParallel
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            model = DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None)
+        model = DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None)
     opt = torch.optim.AdamW(model.parameters(), lr=learning_rate)               # :144
     best_val, best_epoch, best_state = float("inf"), 0, copy.deepcopy(net.state_dict())
     history = []
     for group in range(cfg.max_groups):
         for epoch in range(cfg.epochs_per_group):
+            e = epoch + group * cfg.epochs_per_group
             model.train()
-            order = train_idx[torch.randperm(train_idx.numel(), device=device, generator=generator)]
+            if index_plan is not None:
+                train_batches, val_batches = index_plan(e)
+            else:
+                order = train_idx[torch.randperm(train_idx.numel(), device=device, generator=generator)]
+                if order.numel() < steps * cfg.batch_size and dist is not None:     # wrap a short shard around
+                    order = order.repeat((steps * cfg.batch_size + order.numel() - 1) // order.numel())[:steps * cfg.batch_size]
+                train_batches = [order[k:k + cfg.batch_size] for k in range(0, order.numel(), cfg.batch_size)]
+                val_batches = [val_idx[k:k + cfg.batch_size] for k in range(0, val_idx.numel(), cfg.batch_size)]
             tp = tv = 0.0
             nb = 0
-            for k in range(0, order.numel(), cfg.batch_size):
-                b = order[k:k + cfg.batch_size]
+            for b in train_batches:
                 lo, va = model(s[b])
                 pl, vl = weighted_losses(lo, va, d[b], o[b], t[b])
                 opt.zero_grad(set_to_none=True)
@@ -133,9 +159,18 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                 tv += vl.item()
                 nb += 1
             model.eval()
-            vp, vv = _evaluate(net, tensors, val_idx, cfg.batch_size) if val_idx.numel() else (tp / nb, tv / nb)
+            if dist is not None:                                                 # BatchNorm running statistics: average the ranks'
+                for buf in net.buffers():                                        # (the parameters are already identical)
+                    if buf.is_floating_point():
+                        dist.all_reduce(buf)
+                        buf /= dist.get_world_size()
+            vp, vv, vn = _evaluate(net, tensors, val_batches) if len(val_batches) else (tp, tv, nb)
+            if dist is not None:                                                 # one decision for all ranks
+                sums = torch.tensor([vp, vv, float(vn)], device=device, dtype=torch.float64)
+                dist.all_reduce(sums)
+                vp, vv, vn = float(sums[0]), float(sums[1]), int(round(float(sums[2])))
+            vp, vv = vp / max(1, vn), vv / max(1, vn)
             val_loss = vp + vv
-            e = epoch + group * cfg.epochs_per_group
             history.append(dict(epoch=e, train_policy=tp / nb, train_value=tv / nb, val_policy=vp, val_value=vv))
             if val_loss < best_val:                                              # :210-219
                 best_val, best_epoch = val_loss, e

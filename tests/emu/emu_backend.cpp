@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../sprl_amd/csrc/backend.h"
+#include "../../sprl_amd/csrc/records_kernel.h"
 #include "../../sprl_amd/csrc/step_kernel.h"
 #include "../../sprl_amd/csrc/step_kernel_wide.h"
 
@@ -84,6 +85,43 @@ int launch_compact(const EngineParams& P, int floats_per_leaf) {
     }
     P.counters->leaf_total = run;
     P.counters->leaf_rows += run;
+    return 0;
+}
+int launch_records_scan(const EngineParams& P) {
+    int32_t run = 0;
+    for (int g = 0; g < P.num_games; ++g) {
+        P.rec_offsets[g] = run;
+        run += P.rec_nplies[g];
+    }
+    P.rec_offsets[P.num_games] = run;
+    return 0;
+}
+template <class G>
+static void pack_all(const EngineParams& P, const RecPacked& o, int use_sym) {
+    for (int g = 0; g < P.num_games; ++g)
+        for (int lane = 0; lane < 64; ++lane) rec_pack_game<G>(P, o, g, lane, use_sym);
+}
+template <class G>
+static void expand_all(const EngineParams& P, const RecExpanded& o) {
+    for (int g = 0; g < P.num_games; ++g)
+        for (int lane = 0; lane < 64; ++lane) rec_expand_game<G>(P, o, g, lane);
+}
+int launch_records_pack(int game, const EngineParams& P, const RecPacked& o, int use_sym) {
+    if (game == SPRL_GAME_OTHELLO) pack_all<Othello>(P, o, use_sym);
+    else if (game == SPRL_GAME_CONNECT_FOUR) pack_all<ConnectFour>(P, o, use_sym);
+    else if (game == SPRL_GAME_GO7) pack_all<Go7>(P, o, use_sym);
+    else if (game == SPRL_GAME_GO9) pack_all<GoN<9>>(P, o, use_sym);
+    else if (game == SPRL_GAME_GO19) pack_all<GoN<19>>(P, o, use_sym);
+    else pack_all<GoN<7>>(P, o, use_sym);
+    return 0;
+}
+int launch_records_expand(int game, const EngineParams& P, const RecExpanded& o) {
+    if (game == SPRL_GAME_OTHELLO) expand_all<Othello>(P, o);
+    else if (game == SPRL_GAME_CONNECT_FOUR) expand_all<ConnectFour>(P, o);
+    else if (game == SPRL_GAME_GO7) expand_all<Go7>(P, o);
+    else if (game == SPRL_GAME_GO9) expand_all<GoN<9>>(P, o);
+    else if (game == SPRL_GAME_GO19) expand_all<GoN<19>>(P, o);
+    else expand_all<GoN<7>>(P, o);
     return 0;
 }
 void* mark() {

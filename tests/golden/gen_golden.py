@@ -208,6 +208,90 @@ def g9b_baseline_network():
     save("g9b_baseline_network.npz", **out)
 
 
+def g_trainer():
+    """f-2 fixture: the REFERENCE controller's train_network (scripts/othello_controller.py:128-241) run on a fixed synthetic
+    window - seed-reproducible network weights (netfill.py) and samples - with its group / epoch / batch constants scaled down.
+    Recorded: the batches it drew (its DataLoaders are wrapped, nothing else is touched), the epoch it selected as best and
+    the outputs of the model it saved, so that sprl_amd/trainer.py can be replayed on the same batches and compared."""
+    import contextlib
+    import io
+    import re
+    import torch
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    sys.path.insert(0, OUT)
+    import netfill
+    import scripts.othello_controller as oc           # reference module, this container only (its main() is not run)
+    from src.networks.grid_networks import BasicGridNetwork
+
+    seed, n = 777, 320
+    rs = np.random.RandomState(seed)
+    states = netfill.othello_like_inputs(n, seed)
+    raw = rs.standard_normal((n, 65)).astype(np.float32) * 2.0
+    dists = np.exp(raw) / np.exp(raw).sum(1, keepdims=True)
+    outcomes = rs.randint(-1, 2, size=(n, 1)).astype(np.float32)
+    stamps = (1.0 + np.arange(n, dtype=np.float32) / 1024.0).reshape(n, 1) + rs.randint(0, 3, size=(n, 1)).astype(np.float32)
+    assert len(np.unique(stamps)) == n                 # unique weights: a batch identifies its samples
+    index_of = {float(v): i for i, v in enumerate(stamps[:, 0])}
+
+    batches = []
+
+    class RecordingLoader(oc.DataLoader):
+        def __iter__(self):
+            for b in super().__iter__():
+                batches.append(np.array([index_of[float(v)] for v in b[3][:, 0]], np.int32))
+                yield b
+
+    consts = dict(MAX_GROUPS=3, EPOCHS_PER_GROUP=4, BATCH_SIZE=48, RUN_NAME="fixture", device="cpu")
+    for k, v in consts.items():
+        setattr(oc, k, v)
+    oc.DataLoader = RecordingLoader
+    lr = float(os.environ.get('SPRL_GEN_TRAINER_LR', '0.0005'))
+    with tempfile.TemporaryDirectory() as td:
+        cwd = os.getcwd()
+        os.chdir(td)
+        try:
+            os.makedirs("data/models/fixture")
+            torch.manual_seed(seed)
+            net = netfill.fill_state_dict(BasicGridNetwork(8, 8, 65, 1, 1, 8), seed)
+            buf = io.StringIO()
+            import pickle
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                try:
+                    oc.train_network(net, lr, 0, torch.from_numpy(states), torch.from_numpy(dists.astype(np.float32)),
+                                     torch.from_numpy(outcomes), torch.from_numpy(stamps))
+                except pickle.UnpicklingError:
+                    # the reference's last step, trace_model (src/interface/tracer.py:17), calls torch.load(path) on a pickled
+                    # module, which torch >= 2.6 (weights_only=True by default; the reference pins 2.2.2) refuses: training and
+                    # the best-model file are complete at that point; the trace is redone below exactly as tracer.py:18 does it
+                    pass
+            best_epoch = int(re.search(r"best model was at epoch (\d+)", buf.getvalue()).group(1))
+            best = torch.load("data/models/fixture/fixture_iteration_0.pt", weights_only=False).eval()
+            traced = torch.jit.trace(best, torch.randn(1, 3, 8, 8)).eval()
+            probe = torch.from_numpy(states[:16])
+            with torch.no_grad():
+                lo, va = best(probe)
+                tlo, tva = traced(probe)
+                flo, fva = net.eval()(probe)             # the live network after the last epoch (carried to the next iteration)
+        finally:
+            os.chdir(cwd)
+    n_train = int(0.9 * n)
+    per_epoch_train = -(-n_train // consts["BATCH_SIZE"])
+    per_epoch_val = -(-(n - n_train) // consts["BATCH_SIZE"])
+    epochs = len(batches) // (per_epoch_train + per_epoch_val)
+    assert epochs * (per_epoch_train + per_epoch_val) == len(batches)
+    out = dict(seed=np.array([seed]), n=np.array([n]), lr=np.array([lr]), best_epoch=np.array([best_epoch]), epochs=np.array([epochs]),
+               max_groups=np.array([consts["MAX_GROUPS"]]), epochs_per_group=np.array([consts["EPOCHS_PER_GROUP"]]),
+               batch_size=np.array([consts["BATCH_SIZE"]]), batches_per_epoch=np.array([per_epoch_train, per_epoch_val]),
+               dists=dists.astype(np.float32), outcomes=outcomes, stamps=stamps,
+               best_logits=lo.numpy(), best_value=va.numpy(), traced_logits=tlo.numpy(), traced_value=tva.numpy(),
+               final_logits=flo.numpy(), final_value=fva.numpy())
+    for i, b in enumerate(batches):
+        out[f"batch{i}"] = b
+    save("g_trainer.npz", **out)
+
+
 MATCH_CASES = [  # game, kind0, kind1, games, traversals, batch, queue, sym0, parentQ0, sym1, parentQ1, seed
     ("othello", 0, 1, 6, 64, 8, 4, 1, 1, 1, 1, 777),
     ("othello", 0, 1, 4, 100, 8, 4, 0, 0, 1, 1, 778),
@@ -249,6 +333,9 @@ def g_go9():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        g_trainer()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g9b":
         g9b_baseline_network()
         sys.exit(0)
@@ -264,6 +351,7 @@ if __name__ == "__main__":
     g5_games()
     g7_g9_network()
     g9b_baseline_network()
+    g_trainer()
     g10_matches()
     if pyref.available(variant="go9"):
         g_go9()

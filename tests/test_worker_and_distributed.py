@@ -126,3 +126,42 @@ def test_two_rank_game_sharding_gloo(emu, tmp_path, game, trav, port):
     cells = z["r0_boards"].shape[1]
     assert (np.concatenate([z["r0_boards"], z["r1_boards"]]) == ora["boards"][0::nsym][:, :cells]).all()
     assert (np.concatenate([z["r0_winners"], z["r1_winners"]]).size == 6)
+
+
+@pytest.mark.parametrize("game,kw", [("othello", dict(num_traversals=16)), ("c4", dict(num_traversals=16)), ("go", dict(num_traversals=20)),
+                                     ("go9", dict(num_traversals=20))])
+def test_device_side_pack_and_expand_equal_host_paths(emu, game, kw):
+    """The record kernels (records_kernel.h: same source on the device and here on the emulator) against the host paths:
+    packed bytes == distributed.pack_records(collect()), expanded samples == sprl_records_expand (the reference's arrays)."""
+    from sprl_amd.distributed import pack_records
+    cfg = E.default_config(game, emu, concurrent_games=3, seed=4, **kw)
+    eng = E.Engine(cfg, emu)
+    eng.set_model("random")
+    eng.begin(3)
+    with pytest.raises(E.SprlError):
+        eng.records_info()                                  # nothing has finished yet
+    done = 0
+    while done < 3:
+        done, _ = eng.step(64)
+    plies, samples, nbytes = eng.records_info()
+    packed = np.full(nbytes + 16, 0xAB, np.uint8)
+    base = (-packed.ctypes.data) % 16                       # a 16-byte aligned window inside the buffer
+    eng.pack_records_into(packed.ctypes.data + base, nbytes)
+    rec0 = eng  # keep the engine running for the expansion below
+    A = emu.sprl_records_num_samples                       # noqa: F841 (symbol exists)
+    states = np.full((samples, 2 * (8 if game.startswith("go") else 1) + 1, cfg_rows(game), cfg_rows(game, cols=True)), np.nan, np.float32)
+    dists = np.full((samples, {"othello": 65, "c4": 7, "go": 50, "go9": 82}[game]), np.nan, np.float32)
+    outs = np.full(samples, np.nan, np.float32)
+    eng.expand_records_into(states.ctypes.data, dists.ctypes.data, outs.ctypes.data, samples)
+    rec = eng.collect()                                     # the host path of the same run
+    assert rec.total_plies == plies and rec.num_samples == samples
+    want = pack_records(rec)
+    assert want.size == nbytes and (packed[base:base + nbytes] == want).all()
+    assert (packed[base + nbytes:] == 0xAB).all()
+    s1, d1, o1 = rec.expand()
+    assert (states == s1).all() and (dists.view(np.uint32) == d1.view(np.uint32)).all() and (outs == o1).all()
+    eng.close()
+
+
+def cfg_rows(game, cols=False):
+    return {"othello": (8, 8), "c4": (6, 7), "go": (7, 7), "go9": (9, 9)}[game][1 if cols else 0]

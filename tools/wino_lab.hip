@@ -37,6 +37,36 @@ void sprl_wino_transform_weights_host(const float* g, float* up) {
                 }
         }
 }
+// U' = G' g G'^T (integer G', the row scales live in the V transform), product layout U4[p / 4][s][kb][lane][p % 4]
+void pack_u36_scaled_host(const float* g, float* up) {
+    static const double G[6][3] = { { 1, 0, 0 }, { 1, 1, 1 }, { 1, -1, 1 }, { 1, 2, 4 }, { 1, -2, 4 }, { 0, 0, 1 } };
+    for (int k = 0; k < 64; ++k)
+        for (int c = 0; c < 64; ++c) {
+            const float* gk = g + ((size_t)k * 64 + c) * 9;
+            double t[6][3];
+            for (int a = 0; a < 6; ++a)
+                for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * gk[j] + G[a][1] * gk[3 + j] + G[a][2] * gk[6 + j];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+                    const int p = a * 6 + b, s = 4 * (c >> 4) + (c & 3), kb = k >> 4, lane = ((c >> 2) & 3) * 16 + (k & 15);
+                    up[((((size_t)(p >> 2) * 16 + s) * 4 + kb) * 64 + lane) * 4 + (p & 3)] = (float)v;
+                }
+        }
+}
+// T' = G' g: T4[s][kb][row 6][lane][4] (three values + one pad float per row)
+void pack_t18_host(const float* g, float* out) {
+    static const double G[6][3] = { { 1, 0, 0 }, { 1, 1, 1 }, { 1, -1, 1 }, { 1, 2, 4 }, { 1, -2, 4 }, { 0, 0, 1 } };
+    for (int k = 0; k < 64; ++k)
+        for (int c = 0; c < 64; ++c) {
+            const float* gk = g + ((size_t)k * 64 + c) * 9;
+            const int s = 4 * (c >> 4) + (c & 3), kb = k >> 4, lane = ((c >> 2) & 3) * 16 + (k & 15);
+            for (int a = 0; a < 6; ++a)
+                for (int j = 0; j < 4; ++j)
+                    out[((((size_t)s * 4 + kb) * 6 + a) * 64 + lane) * 4 + j] =
+                        j < 3 ? (float)(G[a][0] * gk[j] + G[a][1] * gk[3 + j] + G[a][2] * gk[6 + j]) : 0.0f;
+        }
+}
 // the 3x3 filters in A-operand lane order: G8[s][kb][2][lane][4] (filter taps 0..7), then G1[s][kb][lane] (tap 8)
 void sprl_wino_pack_g9_host(const float* g, float* out) {
     for (int k = 0; k < 64; ++k)
@@ -90,11 +120,16 @@ int main(int argc, char** argv) {
     for (auto& v : hw) v = nd(rng) * 0.06f;
     for (auto& v : hsc) v = 0.5f + (float)(rng() % 1000) / 1000.0f;
     for (auto& v : hsh) v = nd(rng) * 0.3f;
-    std::vector<float> hu(36 * 64 * 64), hg(G9_FLOATS);
+    std::vector<float> hu(36 * 64 * 64), hg(G9_FLOATS), hus(36 * 64 * 64), ht(24 * 64 * 64);
     sprl_wino_transform_weights_host(hw.data(), hu.data());
     sprl_wino_pack_g9_host(hw.data(), hg.data());
+    pack_u36_scaled_host(hw.data(), hus.data());
+    pack_t18_host(hw.data(), ht.data());
 
-    float *x, *y, *r, *u, *g9, *sc, *sh;
+    float *x, *y, *r, *u, *g9, *sc, *sh, *us, *t18;
+    hipMalloc(&us, hus.size() * 4); hipMalloc(&t18, ht.size() * 4);
+    hipMemcpy(us, hus.data(), hus.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(t18, ht.data(), ht.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMalloc(&r, n * 4);
     hipMalloc(&u, hu.size() * 4); hipMalloc(&g9, hg.size() * 4); hipMalloc(&sc, 256); hipMalloc(&sh, 256);
     hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
@@ -107,9 +142,10 @@ int main(int argc, char** argv) {
 
     std::vector<Variant> vs = {
         { "v2 product (U36 from L2)", launch_v2, 0 },
-        { "v4 G9 + b128 V layout", launch_v4<8>, 1 },
-        { "v4 G9 + b128 + scaled transforms", launch_v4<8 + 16>, 1 },
-        { "v4 G9 + scaled transforms (b32 V)", launch_v4<16>, 1 },
+        { "v4 G9 scaled + row-ahead U + b128", launch_v4<8 + 16 + 2048>, 1 },
+        { "v4 U36' ring (scaled), b32 V", launch_v4<16 + 8192>, 2 },
+        { "v4 U36 ring (unscaled), b32 V", launch_v4<8192>, 0 },
+        { "v4 U36 ring (unscaled), b128 V", launch_v4<8 + 8192>, 0 },
     };
 
     // float64 reference for boards 0..3 and the last board (direct 3x3 convolution, padding 1, + scale/shift + residual + ReLU)
@@ -146,7 +182,7 @@ int main(int argc, char** argv) {
     }
     for (size_t vi = 0; vi < vs.size(); ++vi) {
         hipMemset(y, 0xff, n * 4);
-        vs[vi].launch(x, vs[vi].wkind ? g9 : u, sc, sh, r, y, B);
+        vs[vi].launch(x, vs[vi].wkind == 3 ? t18 : vs[vi].wkind == 2 ? us : vs[vi].wkind ? g9 : u, sc, sh, r, y, B);
         if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", vs[vi].name); return 1; }
         hipMemcpy(hy.data(), y, n * 4, hipMemcpyDeviceToHost);
         double err = 0.0;
@@ -196,7 +232,7 @@ int main(int argc, char** argv) {
         unsigned long long* st;
         hipMalloc(&st, (size_t)ngroups * 16 * 8);
         hipMemset(st, 0, (size_t)ngroups * 16 * 8);
-        for (int rep = 0; rep < 3; ++rep) sprl_wino_conv64_v4_launch<32>(x, g9, sc, sh, r, y, B, 1, nullptr, nullptr, (float*)st);
+        for (int rep = 0; rep < 3; ++rep) sprl_wino_conv64_v4_launch<32 + 8192>(x, u, sc, sh, r, y, B, 1, nullptr, nullptr, (float*)st);
         hipDeviceSynchronize();
         std::vector<unsigned long long> hs((size_t)ngroups * 16);
         hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
@@ -224,7 +260,7 @@ int main(int argc, char** argv) {
     for (int rd = 0; rd < rounds + 1; ++rd)
         for (size_t vi = 0; vi < vs.size(); ++vi) {
             hipEventRecord(e0, 0);
-            for (int i = 0; i < iters; ++i) vs[vi].launch(x, vs[vi].wkind ? g9 : u, sc, sh, r, y, B);
+            for (int i = 0; i < iters; ++i) vs[vi].launch(x, vs[vi].wkind == 3 ? t18 : vs[vi].wkind == 2 ? us : vs[vi].wkind ? g9 : u, sc, sh, r, y, B);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms = 0;
