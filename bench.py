@@ -126,22 +126,42 @@ def cpu_baseline(model_path, traversals, games_per_process=3, max_processes=0):
             "sample": f"1 game, Othello {traversals} it/move, oracle + torch-CPU forward, {r['stats']['nn_evals']} evals"}
 
 
+GAMES = {
+    # game: engine name, board, actions, planes, default concurrent games, traversals, CNN blocks (the reference controllers'
+    # MODEL_NUM_BLOCKS: othello/connect_four 2, go 6), batch/queue (worker constants), label
+    "othello": dict(engine="othello", rows=8, cols=8, A=65, planes=3, concurrent=4096, traversals=800, blocks=2, bq="8/4",
+                    label="Othello 8x8", sym="D4", noise="Dirichlet(0.25,0.3)", mask_bytes=8, board_bytes=64),
+    "connect_four": dict(engine="connect_four", rows=6, cols=7, A=7, planes=3, concurrent=4096, traversals=100, blocks=2, bq="8/4",
+                         label="Connect Four 6x7", sym="mirror", noise="Dirichlet(0.25,0.5)", mask_bytes=8, board_bytes=42),
+    "go7": dict(engine="go7", rows=7, cols=7, A=50, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8",
+                label="Go 7x7", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=8, board_bytes=49),
+    "go9": dict(engine="go9", rows=9, cols=9, A=82, planes=17, concurrent=1024, traversals=1600, blocks=6, bq="16/8",
+                label="Go 9x9", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=11, board_bytes=81),
+    "go19": dict(engine="go19", rows=19, cols=19, A=362, planes=17, concurrent=256, traversals=1600, blocks=6, bq="16/8",
+                 label="Go 19x19", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=46, board_bytes=361),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--game", default="othello", choices=sorted(GAMES),
+                    help="othello = the BASELINE metric (config 2/3); go9 / go19 = BASELINE configs 4 / 5")
     ap.add_argument("--games", type=int, default=0, help="games per GPU per step (default: = --concurrent)")
-    ap.add_argument("--concurrent", type=int, default=4096, help="resident game slots per GPU")
-    ap.add_argument("--traversals", type=int, default=800)
+    ap.add_argument("--concurrent", type=int, default=0, help="resident game slots per GPU (default per game: othello 4096)")
+    ap.add_argument("--traversals", type=int, default=0, help="UCT iterations per move (default per game: othello 800, go 1600)")
     ap.add_argument("--model", default="cnn", choices=["cnn", "random", "heuristic"],
-                    help="cnn = BASELINE config (traced 2x64 CNN via LibTorch-ROCm); random/heuristic = tree kernels only")
-    ap.add_argument("--blocks", type=int, default=2)
+                    help="cnn = BASELINE config (traced CNN via LibTorch-ROCm); random/heuristic = tree kernels only")
+    ap.add_argument("--blocks", type=int, default=0, help="residual blocks of the CNN (default per game: othello 2, go 6)")
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--rounds-per-call", type=int, default=64)
     ap.add_argument("--populations", type=int, default=1,
                     help="split the resident games of a GPU into this many engines, each on its own HIP stream and host thread: "
                          "one population's tree kernel and convolution tails overlap the other's CNN work")
+    ap.add_argument("--resign-threshold", type=float, default=0.0, help="extension (BASELINE config 5), 0 = off as in the reference")
+    ap.add_argument("--resign-min-ply", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
@@ -150,6 +170,10 @@ def main():
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N > 1 code path")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
+    G = GAMES[args.game]
+    args.concurrent = args.concurrent or G["concurrent"]
+    args.traversals = args.traversals or G["traversals"]
+    args.blocks = args.blocks or G["blocks"]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -172,9 +196,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm_device = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+    dev = torch.device("cuda", local_rank)
+    comm_device = dev if args.backend == "nccl" else torch.device("cpu")
 
     from sprl_amd import engine as E
+    from sprl_amd.distributed import gather_packed
     from sprl_amd.network import make_network, trace_to_file
 
     games = args.games or args.concurrent
@@ -182,8 +208,8 @@ def main():
     tmpdir = tempfile.mkdtemp(prefix="sprl_bench_")
     model_path = None
     if args.model == "cnn":
-        model_path = trace_to_file(make_network("othello", args.blocks, args.channels, seed=0),
-                                   os.path.join(tmpdir, f"traced_bench_r{rank}.pt"), "othello")
+        model_path = trace_to_file(make_network(G["engine"], args.blocks, args.channels, seed=0),
+                                   os.path.join(tmpdir, f"traced_bench_r{rank}.pt"), G["engine"])
     total_steps = args.steps + args.warmup
     # unique RNG streams for every game of every step of every rank
     pops = max(1, args.populations)
@@ -192,10 +218,11 @@ def main():
     engines = []
     t_load = time.perf_counter()
     for p in range(pops):
-        cfg = E.default_config("othello", lib, device=local_rank, concurrent_games=args.concurrent // pops,
+        cfg = E.default_config(G["engine"], lib, device=local_rank, concurrent_games=args.concurrent // pops,
                                num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
                                stream_base=1 + (rank * pops + p) * (games // pops) * (total_steps + 2),
-                               profile=0 if args.no_profile else 1, own_stream=1 if pops > 1 else 0)
+                               profile=0 if args.no_profile else 1, own_stream=1 if pops > 1 else 0,
+                               resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
         en = E.Engine(cfg, lib)
         en.set_model(model_path if model_path else args.model)
         engines.append(en)
@@ -208,40 +235,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_records(rec):
-        """RCCL gather of the compact finished-game records to rank 0."""
-        if dist is None:
-            return rec.total_plies
-        from sprl_amd.distributed import gather_records as _gather
-        shards = _gather(rec, dist, device=comm_device)
-        torch.cuda.synchronize()
-        return sum(sh["total_plies"] for sh in shards) if shards is not None else rec.total_plies
-
     gather_s = [0.0]
+    shard_bytes = [0]
 
-    def play(en, n_games, out, k):
+    def emit_records(en):
+        """The finished games' compact records, packed ON THE DEVICE from the engine's record buffers (records_kernel.h).
+        N > 1: the packed shards are gathered to rank 0 by the collective backend on the tensors where they lie (RCCL: device
+        memory, no host bounce - SURVEY section 8e).  N = 1: the shard is copied to the host once (what a worker would write out)."""
+        plies, _, nbytes = en.records_info()
+        shard = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        en.pack_records_into(shard.data_ptr(), nbytes)
+        en.finish()
+        shard_bytes[0] = nbytes
+        if dist is None:
+            host = shard.cpu()
+            return int(host[:16].view(torch.int64)[1])            # head[1] = plies of the shard
+        shards = gather_packed(shard if comm_device.type == "cuda" else shard.cpu(), nbytes, dist)
+        torch.cuda.synchronize()
+        return sum(sh["total_plies"] for sh in shards) if shards is not None else plies
+
+    def play(en, n_games):
         en.begin(n_games)
         done = 0
         while done < n_games:
             done, _ = en.step(args.rounds_per_call)
-        out[k] = en.collect()
 
     def one_step():
-        recs = [None] * pops
         if pops == 1:
-            play(engines[0], games, recs, 0)
+            play(engines[0], games)
         else:                                       # one host thread per population (the C calls release the GIL)
             import threading
-            ths = [threading.Thread(target=play, args=(engines[k], games // pops, recs, k)) for k in range(pops)]
+            ths = [threading.Thread(target=play, args=(engines[k], games // pops)) for k in range(pops)]
             for t in ths:
                 t.start()
             for t in ths:
                 t.join()
         plies = 0
         tg = time.perf_counter()
-        for rec in recs:
-            plies += gather_records(rec)
-            rec.close()
+        for en in engines:
+            plies += emit_records(en)
         gather_s[0] += time.perf_counter() - tg
         return plies
 
@@ -253,6 +285,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+
     def all_stats():
         tot = {}
         for en in engines:
@@ -279,10 +312,11 @@ def main():
 
     if rank == 0:
         total_games = games * args.steps * world
-        bpt, shape = algorithmic_bytes_per_traversal(d)
+        bpt, shape = algorithmic_bytes_per_traversal(d, A=G["A"], mask_bytes=G["mask_bytes"], board_bytes=G["board_bytes"],
+                                                     s_in=G["planes"] * G["rows"] * G["cols"] * 4)
+        backend_name = "RCCL over xGMI (nccl)" if args.backend == "nccl" else "gloo (rehearsal)"
         out = {
-            "metric": "self-play games/sec, Othello 8x8 @ 800 iters/move" if args.traversals == 800 else
-                      f"self-play games/sec, Othello 8x8 @ {args.traversals} iters/move",
+            "metric": f"self-play games/sec, {G['label']} @ {args.traversals} iters/move",
             "value": total_games / elapsed,
             "unit": "games/s",
             "n_gpus": world,
@@ -294,11 +328,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (start-position self-play, random-init weights)",
-            "config": {"workload": f"Othello 8x8, {args.traversals} UCT iters/move, {args.concurrent} concurrent games/GPU, "
-                                   f"{games} games/GPU/step, batch 8/queue 4, D4, Dirichlet(0.25,0.3)" +
+            "config": {"workload": f"{G['label']}, {args.traversals} UCT iters/move, {args.concurrent} concurrent games/GPU, "
+                                   f"{games} games/GPU/step, batch {G['bq'].split('/')[0]}/queue {G['bq'].split('/')[1]}, {G['sym']}, {G['noise']}" +
+                                   (f", resign threshold {args.resign_threshold}" if args.resign_threshold > 0 else "") +
                                    (f", {pops} populations on {pops} HIP streams" if pops > 1 else ""),
                        "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32, " + eng.evaluator_info() if model_path else args.model),
-                       "parallelism": f"game-sharded x{world}, RCCL gather of records" if world > 1 else "1 GPU"},
+                       "parallelism": (f"game-sharded x{world}, records packed on the device, one gather per step over {backend_name}"
+                                       if world > 1 else "1 GPU")},
             "expansions_per_sec": d["expansions"] * world / elapsed,
             "traversals_per_sec": d["traversals"] * world / elapsed,
             "nn_evals_per_sec": d["nn_evals"] * world / elapsed,
@@ -308,7 +344,8 @@ def main():
                       "rounds": d["rounds"], "nn_batches": d["nn_batches"], "nn_rows": d["nn_rows"],
                       "nn_fill": (d["nn_evals"] / d["nn_rows"]) if d["nn_rows"] else None, "hbm_gib": st1["hbm_bytes"] / 2**30, "model_load_and_warmup_s": t_load,
                       "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"],
-                      "record_gather_ms": 1000.0 * gather_s[0]},
+                      "nodes_recycled_share": d["nodes_recycled"] / max(1, d["nodes_created"]),
+                      "record_gather_ms": 1000.0 * gather_s[0] / max(1, args.steps), "record_shard_bytes": shard_bytes[0]},
         }
         if d.get("cyc_total", 0) > 0:
             out["phase_cycles_share"] = {k[4:]: d[k] / d["cyc_total"] for k in d if k.startswith("cyc_") and k not in ("cyc_total", "cyc_max_slot_launch")}
@@ -323,7 +360,7 @@ def main():
             if os.path.exists(tpath):           # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
                 with open(tpath) as tf:
                     traffic = json.load(tf).get("hbm_bytes_per_launch")
-            tree = {"bound": "hbm", "kernel": "step_kernel<Othello> (select/expand/backup/re-root)",
+            tree = {"bound": "hbm", "kernel": f"step_kernel ({G['label']}: select/expand/backup/re-root)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "bytes_per_traversal": bpt,
@@ -333,24 +370,26 @@ def main():
                 # the dominant kernel by time: the trunk convolution of the CNN (cnn_wino.hip), fp32 MFMA-bound.
                 # Algorithmic work per board and launch = the Winograd-domain products the kernel must issue:
                 # 4 tiles x 36 positions x 64 x 64 multiply-adds (4x fewer than the direct 3x3 convolution).
-                flop = d["conv_boards"] * WINO_FLOP_PER_BOARD
+                tiles = ((G["rows"] + 3) // 4) * ((G["cols"] + 3) // 4)
+                flop_per_board = 2 * tiles * 36 * 64 * 64
+                flop = d["conv_boards"] * flop_per_board
                 tf = flop / (d["conv_ms"] * 1e-3) / 1e12
                 ctraffic = None
                 cpath = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
                 if os.path.exists(cpath):
                     with open(cpath) as tf_:
                         ctraffic = json.load(tf_).get("hbm_bytes_per_launch")
-                out["roofline"] = {"bound": "mfma", "kernel": "wino_conv64_v2_kernel<8,8> (3x3 conv 64->64 + BN/residual/ReLU, fp32)",
+                out["roofline"] = {"bound": "mfma", "kernel": "wino_conv64 (3x3 conv 64->64 + BN/residual/ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
                                    "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                                    "traffic": ctraffic, "share_of_step_time": d["conv_ms"] * 1e-3 / elapsed,
                                    "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
                                    "boards_per_launch": d["conv_boards"] / max(1, d["conv_launches"]),
-                                   "flop_per_board": WINO_FLOP_PER_BOARD,
+                                   "flop_per_board": flop_per_board,
                                    "direct_conv_equivalent_tflops": tf * 4.0}
                 out["roofline_tree"] = tree
             else:
                 out["roofline"] = tree
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.game == "othello":
             mp_model = model_path
             if mp_model is None:
                 mp_model = trace_to_file(make_network("othello", args.blocks, args.channels, seed=0),

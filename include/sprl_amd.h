@@ -189,6 +189,15 @@ int sprl_records_expand_boards(const sprl_records* r, int8_t* boards, int8_t* pl
  * _outcomes.npy (byte-identical headers; temp file + rename, outcomes last). */
 int sprl_write_npy(const char* path_prefix, const sprl_records* r);
 
+/* A view of games [first_game, first_game + num_games) of `r` (no copy; valid while `r` is; sprl_records_free on it is a
+ * no-op): one GPU run covers several reference tasks, each task's games go to its own directory (sprl_worker --cover). */
+int sprl_records_slice(const sprl_records* r, int32_t first_game, int32_t num_games, sprl_records* out);
+
+/* Compact record file (NOT a reference format): "SPRLv2\1\0", int64 size, then the packed wire format
+ * described at sprl_engine_pack_records - one entry per ply, symmetries / history / plane encoding applied at load
+ * (sprl_amd/records_v2.py).  Temp file + rename. */
+int sprl_write_v2(const char* path, const sprl_records* r);
+
 const char* sprl_last_error(void);
 /* 1 when the library was built for gfx950 and a usable device is present */
 int sprl_device_available(void);

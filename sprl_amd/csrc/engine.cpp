@@ -1057,6 +1057,58 @@ static int write_npy_f32(const std::string& path, const float* data, const std::
     return rename(tmp.c_str(), path.c_str());
 }
 
+int sprl_records_slice(const sprl_records* r, int32_t first_game, int32_t num_games, sprl_records* out) {
+    if (!r || !out) return fail(SPRL_E_CONFIG, "null argument");
+    if (first_game < 0 || num_games < 1 || first_game + num_games > r->num_games) return fail(SPRL_E_CONFIG, "game range outside the records");
+    *out = *r;
+    const int64_t p0 = r->ply_offset[first_game], p1 = r->ply_offset[first_game + num_games];
+    RecordsOwner* o = new RecordsOwner();                      // only the rebased offsets are owned by the view
+    o->ply_offset.resize((size_t)num_games + 1);
+    for (int i = 0; i <= num_games; ++i) o->ply_offset[(size_t)i] = (int32_t)(r->ply_offset[first_game + i] - p0);
+    out->num_games = num_games;
+    out->total_plies = p1 - p0;
+    out->ply_offset = o->ply_offset.data();
+    out->boards = r->boards + (size_t)p0 * (size_t)r->cells;
+    out->movers = r->movers + p0;
+    out->pdfs = r->pdfs + (size_t)p0 * (size_t)r->actions;
+    out->winners = r->winners + first_game;
+    out->owner_ = o;
+    return 0;
+}
+
+int sprl_write_v2(const char* path, const sprl_records* r) {
+    if (!path || !r) return fail(SPRL_E_CONFIG, "null argument");
+    const int64_t W = (r->cells + 63) / 64, n = r->total_plies, g = r->num_games;
+    const PackedLayout L = packed_layout(g, n, r->actions, W);
+    std::vector<uint8_t> buf((size_t)L.total, 0);
+    const int64_t head[12] = { g, n, r->actions, r->cells, r->game, r->nsym, r->use_symmetry, r->rows, r->cols, W, r->history, 0 };
+    memcpy(buf.data(), head, sizeof(head));
+    memcpy(buf.data() + L.offsets, r->ply_offset, (size_t)(g + 1) * 4);
+    memcpy(buf.data() + L.winners, r->winners, (size_t)g);
+    uint64_t* s0 = (uint64_t*)(buf.data() + L.stones0);
+    uint64_t* s1 = (uint64_t*)(buf.data() + L.stones1);
+    for (int64_t p = 0; p < n; ++p)
+        for (int c = 0; c < r->cells; ++c) {
+            const int8_t v = r->boards[(size_t)p * (size_t)r->cells + (size_t)c];
+            if (v == 0) s0[p * W + (c >> 6)] |= 1ull << (c & 63);
+            else if (v == 1) s1[p * W + (c >> 6)] |= 1ull << (c & 63);
+        }
+    memcpy(buf.data() + L.movers, r->movers, (size_t)n);
+    memcpy(buf.data() + L.pdfs, r->pdfs, (size_t)n * (size_t)r->actions * 4);
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(SPRL_E_IO, "io error: failed to open a file.");
+    const unsigned char magic[8] = { 'S', 'P', 'R', 'L', 'v', '2', 1, 0 };
+    const int64_t size = L.total;
+    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&size, 8, 1, f) == 1 && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        remove(tmp.c_str());
+        return fail(SPRL_E_IO, "io error: failed to write the record file.");
+    }
+    return 0;
+}
+
 int sprl_write_npy(const char* path_prefix, const sprl_records* r) {
     if (!path_prefix || !r) return fail(SPRL_E_CONFIG, "null argument");
     const int64_t n = sprl_records_num_samples(r);

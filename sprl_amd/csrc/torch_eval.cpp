@@ -27,11 +27,6 @@ extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float
                                      float* y, int batch, int H, int W, int relu, void* stream);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
-extern "C" int sprl_wino_conv64_tail(const float* x, const float* u, const float* scale, const float* shift, const float* res,
-                                     int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
-                                     const float* pfc_w, const float* pfc_b, const float* vfc1_w, const float* vfc1_b,
-                                     const float* vfc2_w, const float* vfc2_b, float* logits, float* value, int A, int HID,
-                                     void* stream);
 extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                       int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
                                       float* maps_out, void* stream);

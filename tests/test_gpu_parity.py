@@ -58,7 +58,7 @@ def test_go7_many_games_short_budget(lib):
 
 
 def test_go7_compaction(lib):
-    rec, st = parity.check_case(lib, "go", 4, concurrent_games=4, num_traversals=64, node_cap=200, spare_arenas=4)
+    rec, st = parity.check_case(lib, "go", 4, concurrent_games=4, num_traversals=64, node_cap=200, spare_arenas=4, no_recycle=1)
     assert st["compactions"] > 0
 
 
@@ -80,8 +80,33 @@ def test_go19(lib):
 
 
 def test_compaction_tiny_arena(lib):
+    """Bump allocation + Cheney compaction alone (node recycling off): arenas change owner across XCDs."""
+    rec, st = parity.check_case(lib, "othello", 4, concurrent_games=4, num_traversals=60, node_cap=160, spare_arenas=4, no_recycle=1)
+    assert st["compactions"] > 0 and st["nodes_recycled"] == 0
+
+
+def test_node_recycling_small_arenas(lib):
+    """The nodes of pruned siblings are reused (reference: UCTNode::pruneChildrenExcept frees them, uct/UCTNode.hpp:356-366):
+    whole games stay bit-identical to the oracle, the same tiny arenas now need no compaction, and at the BASELINE budget
+    (800 traversals/move) a game's arena high-water mark stays a few thousand nodes instead of ~36 000."""
     rec, st = parity.check_case(lib, "othello", 4, concurrent_games=4, num_traversals=60, node_cap=160, spare_arenas=4)
-    assert st["compactions"] > 0
+    assert st["compactions"] == 0 and st["nodes_recycled"] > 0.5 * st["nodes_created"] and st["max_nodes_in_arena"] <= 160
+    rec, st = parity.check_case(lib, "go", 4, concurrent_games=4, num_traversals=64, node_cap=260, spare_arenas=4, seed=17)
+    assert st["compactions"] == 0 and st["nodes_recycled"] > 0
+    rec, st = parity.check_case(lib, "othello", 8, concurrent_games=8, num_traversals=800, seed=21)
+    assert st["compactions"] == 0 and st["max_nodes_in_arena"] < 4224 and st["nodes_recycled"] > 0.9 * st["nodes_created"]
+
+
+def test_child_indices_beyond_16_bits(lib, monkeypatch):
+    """Arenas above 65535 nodes: 24-bit child indices (the reference's iteration-0 budget of 131072 traversals per
+    move does not fit 16-bit indices).  The allocator is started next to the boundary (test hook), then a real large budget."""
+    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65400")
+    rec, st = parity.check_case(lib, "othello", 2, concurrent_games=2, num_traversals=40, node_cap=70000, no_recycle=1, seed=3)
+    assert st["max_nodes_in_arena"] > 65535 + 500 and st["compactions"] == 0
+    monkeypatch.delenv("SPRL_TEST_ALLOC_BASE")
+    # a whole game at 65536 traversals/move, batch 1 / queue 1 (the shape of the reference's iteration 0), bit-exact vs the oracle
+    rec, st = parity.check_case(lib, "othello", 1, concurrent_games=1, num_traversals=65536, max_batch=1, max_queue=1, seed=9)
+    assert st["max_nodes_in_arena"] > 65535 and st["compactions"] == 0
 
 
 def test_batch1_queue1_nosym_nonoise(lib):
@@ -440,3 +465,90 @@ def test_resign_threshold_on_device(lib):
     rec, _ = parity.check_case(lib, "go19", 2, concurrent_games=2, num_traversals=24, seed=31, resign_threshold=0.02,
                                resign_min_ply=6)
     assert (rec.ply_offset[1:] - rec.ply_offset[:-1] < 722).all()
+
+
+def test_device_side_records_pack_and_expand(lib):
+    """records_kernel.h on the device: the packed wire format (what ranks hand RCCL) and the expanded training samples,
+    written into torch CUDA tensors, equal the host paths of the same run - Othello and Go 9x9 (two-word bit sets)."""
+    import torch
+    from sprl_amd.distributed import pack_records, unpack_records
+    for game, trav in (("othello", 48), ("go9", 40)):
+        cfg = E.default_config(game, lib, concurrent_games=8, num_traversals=trav, seed=4)
+        eng = E.Engine(cfg, lib)
+        eng.set_model("random")
+        eng.begin(8)
+        done = 0
+        while done < 8:
+            done, _ = eng.step(64)
+        plies, samples, nbytes = eng.records_info()
+        shard = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+        eng.pack_records_into(shard.data_ptr(), nbytes)
+        planes = 17 if game == "go9" else 3
+        side = 9 if game == "go9" else 8
+        A = 82 if game == "go9" else 65
+        states = torch.full((samples, planes, side, side), float("nan"), device="cuda")
+        dists = torch.full((samples, A), float("nan"), device="cuda")
+        outs = torch.full((samples,), float("nan"), device="cuda")
+        eng.expand_records_into(states.data_ptr(), dists.data_ptr(), outs.data_ptr(), samples)
+        torch.cuda.synchronize()
+        rec = eng.collect()
+        want = pack_records(rec)
+        assert want.size == nbytes and (shard.cpu().numpy() == want).all()
+        u = unpack_records(shard.cpu().numpy())
+        assert (u["boards"] == rec.boards).all() and u["words"] == (rec.cells + 63) // 64
+        s1, d1, o1 = rec.expand()
+        assert (states.cpu().numpy() == s1).all() and (outs.cpu().numpy() == o1).all()
+        assert (dists.cpu().numpy().view(np.uint32) == d1.view(np.uint32)).all()
+        eng.close()
+
+
+def test_native_worker_two_iterations_with_model_handover(lib, tmp_path):
+    """The native worker process (sprl_amd/sprl_worker) on the GPU through the reference's file protocol
+    (GridWorker.hpp:35-55,111-197): iteration 0 with the built-in evaluator, then it polls for
+    data/models/<run>/traced_<run>_iteration_0.pt, which a stand-in controller traces and drops while the worker is
+    spinning; iteration 1 and 2 search with that CNN (one engine kept).  Files: reference names, shapes, header bytes;
+    iteration 0 equals the oracle's games bit for bit."""
+    import subprocess
+    import threading
+    import time
+    from sprl_amd.network import make_network, trace_to_file
+    exe = os.path.join(ROOT, "sprl_amd", "sprl_worker")
+    assert os.path.exists(exe), "sprl_amd/sprl_worker not built (make -C sprl_amd/csrc)"
+    run = "gpurun"
+    models = tmp_path / "data" / "models" / run
+    models.mkdir(parents=True)
+    staged = trace_to_file(make_network("othello", 2, 64, seed=5), str(tmp_path / "staged.pt"), "othello")
+
+    def controller():
+        d = tmp_path / "data" / "games" / run / "0" / "0"
+        for it in (0, 1):
+            while not (d / f"{run}_iteration_{it}_outcomes.npy").exists():
+                time.sleep(0.05)
+            time.sleep(0.6)                                   # the worker is polling by now
+            tmp = models / f"tmp_{it}.pt"
+            tmp.write_bytes(open(staged, "rb").read())
+            os.replace(tmp, models / f"traced_{run}_iteration_{it}.pt")
+
+    th = threading.Thread(target=controller)
+    th.start()
+    out = subprocess.run([exe, "othello", "0", "2", "--cover", "2", "--num-tasks-const", "2", "--num-groups", "1", "--num-iters", "3",
+                          "--init-games", "2", "--init-traversals", "64", "--init-max-batch", "8", "--init-max-queue", "4",
+                          "--games", "3", "--traversals", "48", "--seed", "31", "--root", str(tmp_path), "--run-name", run,
+                          "--poll-seconds", "0.3"], capture_output=True, text=True, timeout=600)
+    th.join()
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert out.stdout.count("Spinning on traced model") >= 2 and "Using traced PyTorch network..." in out.stdout
+    for task in (0, 1):
+        d = tmp_path / "data" / "games" / run / "0" / str(task)
+        for it in (0, 1, 2):
+            s = np.load(d / f"{run}_iteration_{it}_states.npy")
+            p = np.load(d / f"{run}_iteration_{it}_distributions.npy")
+            o = np.load(d / f"{run}_iteration_{it}_outcomes.npy")
+            assert s.dtype == np.float32 and s.shape[1:] == (3, 8, 8) and p.shape == (s.shape[0], 65) and o.shape == (s.shape[0],)
+            assert np.allclose(p.sum(1), 1.0, atol=1e-4) and set(np.unique(o).tolist()) <= {-1.0, 0.0, 1.0}
+    ora = po.selfplay(po.make_config(po.GAME_OTHELLO, 64, math_mode=po.MATH_PORTABLE), 4, 31, 1, True)
+    split = ora["offsets"][2]
+    d0 = np.load(tmp_path / f"data/games/{run}/0/0/{run}_iteration_0_distributions.npy")
+    d1 = np.load(tmp_path / f"data/games/{run}/0/1/{run}_iteration_0_distributions.npy")
+    assert (d0.view(np.uint32) == ora["dists"][:split].view(np.uint32)).all()
+    assert (d1.view(np.uint32) == ora["dists"][split:].view(np.uint32)).all()

@@ -165,3 +165,81 @@ def test_device_side_pack_and_expand_equal_host_paths(emu, game, kw):
 
 def cfg_rows(game, cols=False):
     return {"othello": (8, 8), "c4": (6, 7), "go": (7, 7), "go9": (9, 9)}[game][1 if cols else 0]
+
+
+def _native_worker():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    return os.path.join(EMU_DIR, "sprl_worker_emu")
+
+
+def test_native_worker_process_contract(tmp_path):
+    """The native worker (sprl_amd/csrc/worker_main.cpp, here linked against the emulator library): reference argv and exit
+    codes (OTHWorker.cpp:34-42), directory scheme, init vs steady-state budgets, the model-file rendez-vous of
+    GridWorker.hpp:35-55 (the file appears while the worker is polling), one engine across steady-state iterations,
+    --cover with per-task files whose bytes equal the oracle's games, and the v2 compact format."""
+    import threading
+    import time
+    exe = _native_worker()
+    assert subprocess.run([exe, "othello"], capture_output=True).returncode == 1
+    assert subprocess.run([exe, "othello", "0", "12"], capture_output=True).returncode == 1         # the reference asserts 384
+    assert subprocess.run([exe, "pentago", "0", "1"], capture_output=True).returncode == 1
+    common = ["connect_four", "1", "4", "--cover", "2", "--num-tasks-const", "4", "--num-groups", "2", "--num-iters", "3",
+              "--games", "1", "--traversals", "20", "--init-games", "2", "--init-traversals", "30", "--init-max-batch", "8",
+              "--init-max-queue", "4", "--seed", "77", "--root", str(tmp_path), "--run-name", "tinyrun", "--poll-seconds", "0.3",
+              "--evaluator-override", "random"]
+    models = tmp_path / "data" / "models" / "tinyrun"
+    models.mkdir(parents=True)
+
+    def controller():                       # the traced model of iteration i appears some time after iteration i's records
+        for it in (0, 1):
+            d = tmp_path / "data" / "games" / "tinyrun" / "0" / "1"
+            while not (d / f"tinyrun_iteration_{it}_outcomes.npy").exists():
+                time.sleep(0.05)
+            time.sleep(0.5)
+            (models / f"traced_tinyrun_iteration_{it}.pt").write_bytes(b"stand-in")
+
+    th = threading.Thread(target=controller)
+    th.start()
+    out = subprocess.run([exe] + common, capture_output=True, text=True, timeout=240)
+    th.join()
+    assert out.returncode == 0, out.stderr
+    log = out.stdout
+    assert "Task 1 of 4, in group 0" in log and "Starting iteration 2..." in log and "Using initial network..." in log
+    assert log.count("Spinning on traced model from iteration") >= 2           # it really waited for both files
+    for task, group in ((1, 0), (2, 1)):    # group = task // (4 // 2)
+        d = tmp_path / "data" / "games" / "tinyrun" / str(group) / str(task)
+        for it, games in ((0, 2), (1, 1), (2, 1)):
+            s = np.load(d / f"tinyrun_iteration_{it}_states.npy")
+            p = np.load(d / f"tinyrun_iteration_{it}_distributions.npy")
+            o = np.load(d / f"tinyrun_iteration_{it}_outcomes.npy")
+            assert s.dtype == np.float32 and s.shape[1:] == (3, 6, 7) and p.shape == (s.shape[0], 7) and o.shape == (s.shape[0],)
+        assert not list(d.glob("*.tmp"))
+    # iteration 0 = games 0-1 (task 1) and 2-3 (task 2) of one oracle run with streams 1..4
+    cfg = po.make_config(po.GAME_C4, 30, math_mode=po.MATH_PORTABLE)
+    ora = po.selfplay(cfg, 4, 77, 1, True)
+    split = ora["offsets"][2]
+    d1 = np.load(tmp_path / "data/games/tinyrun/0/1/tinyrun_iteration_0_distributions.npy")
+    d2 = np.load(tmp_path / "data/games/tinyrun/1/2/tinyrun_iteration_0_distributions.npy")
+    assert (d1.view(np.uint32) == ora["dists"][:split].view(np.uint32)).all()
+    assert (d2.view(np.uint32) == ora["dists"][split:].view(np.uint32)).all()
+    # iterations 1 and 2 ran on ONE engine: its stream numbering continued (streams 5-6, then 7-8)
+    ora1 = po.selfplay(po.make_config(po.GAME_C4, 20, math_mode=po.MATH_PORTABLE), 2, 77, 5, True)
+    ora2 = po.selfplay(po.make_config(po.GAME_C4, 20, math_mode=po.MATH_PORTABLE), 2, 77, 7, True)
+    for it, ora_it in ((1, ora1), (2, ora2)):
+        a = np.load(tmp_path / f"data/games/tinyrun/0/1/tinyrun_iteration_{it}_distributions.npy")
+        b = np.load(tmp_path / f"data/games/tinyrun/1/2/tinyrun_iteration_{it}_distributions.npy")
+        assert (np.concatenate([a, b]).view(np.uint32) == ora_it["dists"].view(np.uint32)).all()
+    # the worker's .npy bytes are the reference writer's (g5 fixture: C4, 3 games @100, one global stream is a different run;
+    # here: header layout)
+    raw = open(tmp_path / "data/games/tinyrun/0/1/tinyrun_iteration_0_states.npy", "rb").read()
+    assert raw[:8] == b"\x93NUMPY\x01\x00" and (10 + raw[8] + 256 * raw[9]) % 16 == 0
+    # compact format behind a flag (SURVEY section 8f-4)
+    from sprl_amd import records_v2
+    out = subprocess.run([exe, "othello", "0", "1", "--num-tasks-const", "1", "--num-groups", "1", "--num-iters", "1", "--init-games", "2",
+                          "--init-traversals", "24", "--init-max-batch", "8", "--init-max-queue", "4", "--seed", "5", "--root", str(tmp_path),
+                          "--run-name", "v2run", "--format", "v2"], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr
+    s2, d2_, o2 = records_v2.load_compact(str(tmp_path / "data/games/v2run/0/0/v2run_iteration_0.sprl2"))
+    ora = po.selfplay(po.make_config(po.GAME_OTHELLO, 24, math_mode=po.MATH_PORTABLE), 2, 5, 1, True)
+    assert (d2_.view(np.uint32) == ora["dists"].view(np.uint32)).all() and (o2 == ora["outcomes"]).all()
+    assert s2.shape == (len(ora["players"]), 3, 8, 8)

@@ -1,7 +1,8 @@
 // Experiment bench for the trunk convolution (diagnostic, never shipped): variants of the Winograd/MFMA kernel timed in
 // interleaved rounds in ONE process on random data, each checked against a float64 direct convolution on the host.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/wino_lab tools/wino_lab.hip && tools/wino_lab [boards] [rounds]
-#include "../sprl_amd/csrc/cnn_wino.hip"
+#include "wino_variants.hip"   // the experimental variants (v2 = round-1 kernel, v4 = flag-switched experiments); the product kernel
+                               // (sprl_amd/csrc/cnn_wino.hip) is variant v4<8192>: filters as U36 through a register ring
 
 #include <algorithm>
 #include <cmath>
