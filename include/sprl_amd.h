@@ -92,6 +92,10 @@ void sprl_engine_destroy(sprl_engine* e);
  * (networks/GridNetwork.hpp:99-102), which is evaluated on the GPU through LibTorch-ROCm. */
 int sprl_engine_set_model(sprl_engine* e, const char* model);
 
+/* The same from a TorchScript archive in host memory (torch.jit.save(traced, buffer)): the trainer hot-swaps the model
+ * in-process, no file and no polling (selfplay/GridWorker.hpp:35-55 is the file rendez-vous this replaces). */
+int sprl_engine_set_model_buffer(sprl_engine* e, const void* torchscript_bytes, int64_t nbytes);
+
 /* Human-readable description of the evaluator in use (which network execution path was selected). */
 int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len);
 

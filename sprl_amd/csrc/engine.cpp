@@ -77,6 +77,7 @@ int map_action(int game, int sym, int a) {
 struct TorchPlugin {
     void* lib = nullptr;
     void* (*load)(const char*, int, char*, int) = nullptr;
+    void* (*load_buffer)(const void*, long long, int, char*, int) = nullptr;
     int (*forward)(void*, const float*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
     void (*release)(void*) = nullptr;
     int (*is_native)(void*) = nullptr;
@@ -160,6 +161,7 @@ int load_torch_plugin(sprl_engine* e) {
     if (!lib) return fail(SPRL_E_MODEL, std::string("cannot load LibTorch evaluator plugin: ") + dlerror());
     e->torch.lib = lib;
     e->torch.load = (void* (*)(const char*, int, char*, int))dlsym(lib, "sprl_torch_load");
+    e->torch.load_buffer = (void* (*)(const void*, long long, int, char*, int))dlsym(lib, "sprl_torch_load_buffer");
     e->torch.forward = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, char*, int))dlsym(lib, "sprl_torch_forward");
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
     e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
@@ -174,12 +176,14 @@ int load_torch_plugin(sprl_engine* e) {
 
 // Load a traced model through the LibTorch plugin and touch every batch shape the round loop can produce (multiples
 // of the bucket) once, so that the convolution library's per-shape solver selection happens here and not inside a run.
-int load_network(sprl_engine* e, const char* model, void** out) {
+int load_network(sprl_engine* e, const char* model, void** out, const void* bytes = nullptr, int64_t nbytes = 0) {
     int rc = load_torch_plugin(e);
     if (rc) return rc;
     char err[512] = { 0 };
-    void* m = e->torch.load(model, e->cfg.device, err, (int)sizeof(err));
-    if (!m) return fail(SPRL_E_MODEL, std::string("cannot load TorchScript model '") + model + "': " + err);
+    if (bytes && !e->torch.load_buffer) return fail(SPRL_E_MODEL, "LibTorch evaluator plugin lacks sprl_torch_load_buffer");
+    void* m = bytes ? e->torch.load_buffer(bytes, (long long)nbytes, e->cfg.device, err, (int)sizeof(err))
+                    : e->torch.load(model, e->cfg.device, err, (int)sizeof(err));
+    if (!m) return fail(SPRL_E_MODEL, std::string("cannot load TorchScript model '") + (model ? model : "<memory>") + "': " + err);
     // The hand-written CNN (plugin kind 2) has no per-shape solver selection, so its batches are padded to 64 rows only;
     // library convolutions pick a solver per shape, so those batches come in 1024-row buckets, each touched once here.
     const int kind = e->torch.is_native ? e->torch.is_native(m) : 0;
@@ -343,9 +347,8 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     // Node recycling (single-strip kernel): an arena holds the live subtree + the garbage not yet reused, so its size follows
     // the per-move budget, not the game length.  High-water marks measured over whole games: Othello @800 1 291 nodes,
     // Connect Four @512 673, Go 7x7 @400 487 - 4 x traversals + 1024 leaves a 3-5x margin; compaction
-    // into a spare arena remains the fallback.
-    // Boards wider than 8x8 (multi-strip kernel): bump allocation + compaction, 16-bit child indices.
-    P.recycle = (single_strip && cfg->max_batch + 2 <= SPRL_FCACHE && !cfg->no_recycle) ? 1 : 0;
+    // into a spare arena remains the fallback.  Boards wider than 8x8 (multi-strip kernel): the same, with 16-bit child indices.
+    P.recycle = (cfg->max_batch + 2 <= SPRL_FCACHE && !cfg->no_recycle) ? 1 : 0;
     long cap = cfg->node_cap > 0 ? cfg->node_cap
                : P.recycle     ? (long)cfg->num_traversals * 4 + 1024
                                : (long)cfg->num_traversals * 52 + 1024;
@@ -410,22 +413,33 @@ void sprl_engine_destroy(sprl_engine* e) {
     delete e;
 }
 
+static int set_model_common(sprl_engine* e, const char* model, const void* bytes, int64_t nbytes);
+
 int sprl_engine_set_model(sprl_engine* e, const char* model) {
     if (!e || !model) return fail(SPRL_E_CONFIG, "null argument");
+    return set_model_common(e, model, nullptr, 0);
+}
+
+int sprl_engine_set_model_buffer(sprl_engine* e, const void* torchscript_bytes, int64_t nbytes) {
+    if (!e || !torchscript_bytes || nbytes <= 0) return fail(SPRL_E_CONFIG, "null argument");
+    return set_model_common(e, nullptr, torchscript_bytes, nbytes);
+}
+
+static int set_model_common(sprl_engine* e, const char* model, const void* bytes, int64_t nbytes) {
     be::bind(e->cfg.device, e->stream);
     if (e->running) return fail(SPRL_E_STATE, "cannot change the evaluator while a run is in progress");
     e->dev_batch = false;
-    if (strcmp(model, "random") == 0) {          // GridWorker.hpp:36-38,125-127
+    if (model && strcmp(model, "random") == 0) {          // GridWorker.hpp:36-38,125-127
         e->eval_kind = SPRL_EVAL_RANDOM;
         return 0;
     }
-    if (strcmp(model, "heuristic") == 0) {
+    if (model && strcmp(model, "heuristic") == 0) {
         if (e->cfg.game != SPRL_OTHELLO) return fail(SPRL_E_CONFIG, "the heuristic evaluator exists for Othello only");
         e->eval_kind = SPRL_EVAL_HEURISTIC;
         return 0;
     }
     void* m = nullptr;
-    int rc = load_network(e, model, &m);
+    int rc = load_network(e, model, &m, bytes, nbytes);
     if (rc) return rc;
     if (e->torch_model) e->torch.release(e->torch_model);
     e->torch_model = m;

@@ -43,6 +43,7 @@ struct WaveLdsW {
     uint32_t xu[G::STRIPS * 64];
     uint32_t xl[G::STRIPS * 64];              // liberties per group label
     Bits<G::WORDS> xg[G::STRIPS * 64];
+    uint32_t fcache[SPRL_FCACHE];             // recycled node ids ready for reuse (GameCtl::fcache while the slot runs)
 };
 
 template <class G> SPRL_DEV uint8_t* node_at(uint8_t* abase, uint32_t idx) { return abase + (size_t)idx * G::NODE_BYTES; }
@@ -59,11 +60,12 @@ struct GameW {
     Pcg32 rng;
     uint8_t* abase;
     uint32_t arena, root, n_alloc, epoch, root_player, game_id, status;
+    uint32_t rstack_n, fc_n;     // node recycling: reclaim stack height, ready recycled ids (as step_kernel.h)
     float rootN, rootW;
     int ply, traversals, n_leaves;
     int legal_form;         // EngineParams::go_legal_form
     uint32_t d_traversals, d_levels, d_expansions, d_nn_evals, d_terminal, d_gray, d_dup, d_created, d_compactions,
-        d_games, d_plies;
+        d_games, d_plies, d_recycled, hi_alloc;
 };
 
 SPRL_DEV void raise_error(const EngineParams& P, GameW& g, uint32_t code) {
@@ -71,6 +73,63 @@ SPRL_DEV void raise_error(const EngineParams& P, GameW& g, uint32_t code) {
         if (wv::atomic_cas_u32(&P.counters->error, 0u, code) == 0u) P.counters->error_game = g.game_id;
     }
     g.status = ST_ERROR;
+}
+
+// ---- node recycling (see step_kernel.h): the old decision node, its edge to the kept child cut, goes on the game's reclaim
+// stack; refills pop ids, push their children (all strips of the child row + the pass child) and hand the ids to the allocator
+template <class G>
+SPRL_DEV uint32_t alloc_node(GameW& g, WaveLdsW<G>* lds) {
+    if (g.fc_n > 0) {
+        g.d_recycled++;
+        return lds->fcache[--g.fc_n];
+    }
+    const uint32_t c = g.n_alloc++;
+    if (g.n_alloc > g.hi_alloc) g.hi_alloc = g.n_alloc;
+    return c;
+}
+
+template <class G>
+SPRL_DEV void reclaim_refill(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds) {
+    const int l = wv::lane();
+    uint32_t* stack = P.reclaim + (size_t)slot * (size_t)P.node_cap;
+    constexpr int K = WS > 2 ? 2 : 4;         // ids per pass: their child rows (WS strips each) are requested together
+    while (g.fc_n < SPRL_FCACHE && g.rstack_n > 0) {
+        int k = SPRL_FCACHE - (int)g.fc_n;
+        if (k > K) k = K;
+        if (k > (int)g.rstack_n) k = (int)g.rstack_n;
+        const uint32_t base = g.rstack_n - (uint32_t)k;
+        const uint32_t mine = l < k ? stack[base + l] : 0u;
+        wv::sync();
+        g.rstack_n = base;
+        uint32_t id[K], ch[K][WS], pc[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            id[j] = wv::bcast_u32(mine, j < k ? j : 0);
+            uint8_t* np = node_at<G>(g.abase, id[j]);
+#pragma unroll
+            for (int st = 0; st < WS; ++st) ch[j][st] = j < k ? (uint32_t)rowC<G>(np)[st * 64 + l] : (uint32_t)SPRL_NONE16;
+            pc[j] = j < k ? hdr_of<G>(np)->passChild : (uint32_t)SPRL_NONE16;
+        }
+        wv::sync();
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j >= k) break;
+#pragma unroll
+            for (int st = 0; st < WS; ++st) {
+                const bool has = ch[j][st] != SPRL_NONE16;
+                const uint64_t mask = wv::ballot(has);
+                if (has) stack[g.rstack_n + (uint32_t)wv::popc64(mask & wv::lt_mask(l))] = ch[j][st];
+                g.rstack_n += (uint32_t)wv::popc64(mask);
+            }
+            if (pc[j] != SPRL_NONE16) {
+                if (l == 0) stack[g.rstack_n] = pc[j];
+                g.rstack_n += 1;
+            }
+            if (l == 0) lds->fcache[g.fc_n] = id[j];
+            g.fc_n += 1;
+        }
+        wv::wave_fence();
+    }
 }
 
 template <class G>
@@ -548,7 +607,7 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
             bool created = false;
             PosW<G::WORDS> cs;
             if (c == SPRL_NONE16) {
-                c = g.n_alloc++;
+                c = alloc_node<G>(g, lds);
                 created = true;
                 make_child<G>(g, lds, pos_of<G>(h), a, g.ply + depth, cs);
                 write_new_node<G>(node_at<G>(g.abase, c), cs, a);
@@ -678,6 +737,8 @@ SPRL_DEV bool compact_arena(const EngineParams& P, GameW& g) {
     g.abase = to;
     g.root = 0;
     g.n_alloc = free_;
+    g.rstack_n = 0;                           // the garbage stayed behind in the arena that was given back
+    g.fc_n = 0;
     g.d_compactions++;
     return true;
 }
@@ -699,6 +760,8 @@ SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>*
     write_new_node<G>(node_at<G>(g.abase, 0), s, 0);
     g.root = 0;
     g.n_alloc = 1;
+    g.rstack_n = 0;
+    g.fc_n = 0;
     g.epoch = 1;
     g.root_player = 0;
     g.rootN = 0.0f;
@@ -813,9 +876,19 @@ SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* l
     if (c == SPRL_NONE16) {
         PosW<G::WORDS> cs;
         make_child<G>(g, lds, pos_of<G>(h), action, g.ply + 1, cs);
-        c = g.n_alloc++;
+        c = alloc_node<G>(g, lds);
         write_new_node<G>(node_at<G>(g.abase, c), cs, action);
         w_a = (h.flags & F_EVAL) ? h.value : 0.0f;
+    } else if (P.recycle) {                   // pruneChildrenExcept: cut the edge to the kept child, the rest is garbage
+        if (action == WPASS) hdr_of<G>(np)->passChild = SPRL_NONE16;
+        else if ((action & 63) == l) rowC<G>(np)[action] = (uint16_t)SPRL_NONE16;
+        wv::wave_fence();
+    }
+    if (P.recycle) {
+        uint32_t* stack = P.reclaim + (size_t)slot * (size_t)P.node_cap;
+        if (l == 0) stack[g.rstack_n] = g.root;
+        g.rstack_n += 1;
+        wv::wave_fence();
     }
     g.root = c;
     g.rootN = n_a;
@@ -857,8 +930,12 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
     g.traversals = ctl->traversals;
     g.n_leaves = ctl->n_leaves;
     g.root_player = ctl->root_player;
+    g.rstack_n = ctl->rstack_n;
+    g.fc_n = ctl->fc_n;
+    if (wv::lane() < SPRL_FCACHE) lds->fcache[wv::lane()] = ctl->fcache[wv::lane()];
+    g.hi_alloc = g.n_alloc;
     g.d_traversals = g.d_levels = g.d_expansions = g.d_nn_evals = g.d_terminal = g.d_gray = g.d_dup = 0;
-    g.d_created = g.d_compactions = g.d_games = g.d_plies = 0;
+    g.d_created = g.d_compactions = g.d_games = g.d_plies = g.d_recycled = 0;
     g.legal_form = P.go_legal_form;
     g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * G::NODE_BYTES;
     wv::sync();
@@ -893,9 +970,13 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
             }
         }
         if (idle || g.status != ST_ACTIVE) break;
-        if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) {
-            if (!compact_arena<G>(P, g)) break;
-            if (g.n_alloc + (uint32_t)P.max_batch + 1u > (uint32_t)P.node_cap) { raise_error(P, g, ERR_ARENA_FULL); break; }
+        {   // `need` nodes before a search batch: recycled ids, then fresh arena space, then (rarely) a compaction
+            const uint32_t need = (uint32_t)P.max_batch + 1u;
+            if (P.recycle && g.fc_n < need && g.rstack_n > 0) reclaim_refill<G>(P, g, slot, lds);
+            if (g.fc_n + ((uint32_t)P.node_cap - g.n_alloc) < need) {
+                if (!compact_arena<G>(P, g)) break;
+                if ((uint32_t)P.node_cap - g.n_alloc < need) { raise_error(P, g, ERR_ARENA_FULL); break; }
+            }
         }
         select_batch<G>(P, g, slot, ctl, lds);
         ++round;
@@ -916,6 +997,10 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
     ctl->traversals = g.traversals;
     ctl->n_leaves = g.n_leaves;
     ctl->root_player = g.root_player;
+    ctl->rstack_n = g.rstack_n;
+    ctl->fc_n = g.fc_n;
+    wv::sync();
+    if (wv::lane() < SPRL_FCACHE) ctl->fcache[wv::lane()] = lds->fcache[wv::lane()];
     if (wv::lane() == 0) {
         GameStats& t = ctl->stats;
         t.traversals += g.d_traversals;
@@ -929,7 +1014,8 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
         t.compactions += g.d_compactions;
         t.games += g.d_games;
         t.plies += g.d_plies;
-        if (g.n_alloc > t.max_alloc) t.max_alloc = g.n_alloc;
+        t.nodes_recycled += g.d_recycled;
+        if (g.hi_alloc > t.max_alloc) t.max_alloc = g.hi_alloc;
     }
     P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
     if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);

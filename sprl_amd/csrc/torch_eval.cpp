@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,8 @@ extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float
                                      float* y, int batch, int H, int W, int relu, void* stream);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                      long long batch, int P, int H, int W, void* stream);
 extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                       int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
                                       float* maps_out, void* stream);
@@ -270,8 +273,17 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
         if (!forward_wino(mdl, in, p, v, prof, logits_out, value_out, wrote_outputs)) return false;
         if (*wrote_outputs) return true;
     } else {
-        at::Tensor x = at::conv2d(in, n.stem_w, {}, 1, 1);
-        if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
+        at::Tensor x;
+        if ((P0 == 3 || P0 == 17) && n.stem_w.size(0) == 64 && in.is_contiguous() && !getenv("SPRL_TORCH_NO_NCHW_STEM")) {
+            // hand-written stem for any board size (Go 9x9 / 19x19): conv + folded BN + ReLU in one kernel
+            x = at::empty({ in.size(0), 64, H0, W0 }, in.options());
+            if (sprl_stem_conv3x3_nchw(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
+                                       n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), in.size(0), P0, H0, W0, nullptr) != 0)
+                return false;
+        } else {
+            x = at::conv2d(in, n.stem_w, {}, 1, 1);
+            if (!x.is_contiguous() || !epilogue(x, n.stem_scale, n.stem_shift, nullptr)) return false;
+        }
         // boards wider than 8: the trunk still runs on the hand-written Winograd/MFMA kernel (any-board variant, NCHW);
         // the stem (P planes) and the heads keep the library convolution / the NCHW heads kernel
         const bool trunk_wino = n.wino && H0 <= 64 && W0 <= 64 && !getenv("SPRL_TORCH_NO_WINOGRAD_NCHW");
@@ -353,7 +365,17 @@ void put_err(char* err, int errlen, const std::string& msg) {
 
 extern "C" {
 
-void* sprl_torch_load(const char* path, int device, char* err, int errlen) {
+static void* load_common(const char* path, const void* bytes, long long nbytes, int device, char* err, int errlen);
+
+void* sprl_torch_load(const char* path, int device, char* err, int errlen) { return load_common(path, nullptr, 0, device, err, errlen); }
+
+// the same from a TorchScript archive held in memory (torch.jit.save into a buffer): the trainer hands a new model to the
+// engine without a file
+void* sprl_torch_load_buffer(const void* bytes, long long nbytes, int device, char* err, int errlen) {
+    return load_common(nullptr, bytes, nbytes, device, err, errlen);
+}
+
+static void* load_common(const char* path, const void* bytes, long long nbytes, int device, char* err, int errlen) {
     // MIOpen's solver search benchmarks its im2col+GEMM family one image at a time (2.2 M tiny launches for our 16
     // batch shapes, ~20 s) and never picks it for these 3x3 convolutions; leave it out of the search unless the user
     // has set the variable.
@@ -366,8 +388,13 @@ void* sprl_torch_load(const char* path, int device, char* err, int errlen) {
         }
         auto* m = new Model();
         m->device = device;
-        m->module = torch::jit::load(path, device >= 0 ? torch::Device(torch::kCUDA, (c10::DeviceIndex)device)
-                                                       : torch::Device(torch::kCPU));
+        const torch::Device where = device >= 0 ? torch::Device(torch::kCUDA, (c10::DeviceIndex)device) : torch::Device(torch::kCPU);
+        if (path) {
+            m->module = torch::jit::load(path, where);
+        } else {
+            std::istringstream in(std::string((const char*)bytes, (size_t)nbytes), std::ios::binary);
+            m->module = torch::jit::load(in, where);
+        }
         m->module.eval();                       // GridNetwork.hpp:67
         if (device >= 0 && !getenv("SPRL_TORCH_NO_NATIVE")) build_native(m);
         if (!getenv("SPRL_TORCH_NO_REWRITE")) {

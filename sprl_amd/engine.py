@@ -106,6 +106,7 @@ def load_library(path=None):
     L.sprl_engine_destroy.argtypes = [C.c_void_p]
     L.sprl_engine_destroy.restype = None
     L.sprl_engine_set_model.argtypes = [C.c_void_p, C.c_char_p]
+    L.sprl_engine_set_model_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.sprl_engine_set_forward.argtypes = [C.c_void_p, FORWARD_FN, C.c_void_p]
     L.sprl_engine_evaluator_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.sprl_engine_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Records)]
@@ -124,6 +125,8 @@ def load_library(path=None):
     L.sprl_records_expand.argtypes = [C.POINTER(Records), C.c_void_p, C.c_void_p, C.c_void_p]
     L.sprl_records_expand_boards.argtypes = [C.POINTER(Records), C.c_void_p, C.c_void_p]
     L.sprl_write_npy.argtypes = [C.c_char_p, C.POINTER(Records)]
+    L.sprl_write_v2.argtypes = [C.c_char_p, C.POINTER(Records)]
+    L.sprl_records_slice.argtypes = [C.POINTER(Records), C.c_int32, C.c_int32, C.POINTER(Records)]
     L.sprl_match_play.argtypes = [C.POINTER(Config), C.POINTER(MatchAgent), C.POINTER(MatchAgent), C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     _libs[path] = L
@@ -220,6 +223,15 @@ class Engine:
 
     def set_model(self, model):
         self._check(self._lib.sprl_engine_set_model(self._h, os.fsencode(model)))
+
+    def set_model_module(self, traced):
+        """Hot swap: a traced / scripted torch module goes to the evaluator through memory (no .pt file on disk)."""
+        import io
+        import torch
+        buf = io.BytesIO()
+        torch.jit.save(traced, buf)
+        raw = buf.getvalue()
+        self._check(self._lib.sprl_engine_set_model_buffer(self._h, raw, len(raw)))
 
     def set_forward(self, fn):
         """fn(planes_ptr, batch, logits_ptr, value_ptr) -> int, all DEVICE pointers (ints)."""

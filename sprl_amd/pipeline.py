@@ -3,9 +3,11 @@
 The reference couples its two halves through a shared directory: workers poll for `traced_<run>_iteration_<i>.pt`
 every 30 s (cpp/src/selfplay/GridWorker.hpp:35-55), the controller polls for the three `.npy` files every 10 s
 (scripts/othello_controller.py:66-125) and re-reads fp32-expanded samples from disk.  Here one loop owns both: the
-engine's compact records are expanded once, go to HBM as tensors (the trainer's replay window), and the newly
-trained model is handed back to the engine with `set_model` — no polling, no `.npy` round trip.  The reference file
-layout can still be written alongside (`write_files=True`) so the reference tooling keeps working.
+engine's compact records are expanded ON THE DEVICE straight into the tensors of the trainer's replay window
+(sprl_engine_expand_records: no host copy of the records, no fp32 x8 expansion on the CPU), and the newly trained
+network goes back to the engine through memory (sprl_engine_set_model_buffer: a TorchScript archive in a buffer, no
+`.pt` file, no polling).  One engine serves all steady-state iterations.  The reference file layout can still be
+written alongside (`write_files=True`) so the reference tooling keeps working.
 """
 import os
 import tempfile
@@ -59,7 +61,9 @@ class SelfPlayTrainLoop:
         self.window = T.ReplayWindow(self.tcfg, self.train_device)
         self.root = cfg.root or tempfile.mkdtemp(prefix="sprl_loop_")
         os.makedirs(os.path.join(self.root, "data", "models", cfg.run_name), exist_ok=True)
-        self.model_path = None                      # None = iteration 0: the built-in initial evaluator ("random")
+        self.model_path = None                      # the traced file of the last iteration (kept for the reference tooling)
+        self.traced = None                          # None = iteration 0: the built-in initial evaluator ("random")
+        self._eng, self._eng_sig = None, None
         self.next_stream = 1
         self.history = []
 
@@ -67,30 +71,48 @@ class SelfPlayTrainLoop:
         c = self.cfg
         first = iteration == 0
         games = c.init_games if first else c.games
-        kw = dict(device=c.device, concurrent_games=min(c.concurrent_games or games, games),
-                  num_traversals=c.init_traversals if first else c.traversals,
-                  max_batch=c.init_max_batch if first else c.max_batch,
-                  max_queue=c.init_max_queue if first else c.max_queue, seed=c.seed, stream_base=self.next_stream)
+        sig = (min(c.concurrent_games or games, games), c.init_traversals if first else c.traversals,
+               c.init_max_batch if first else c.max_batch, c.init_max_queue if first else c.max_queue)
+        if self._eng is None or sig != self._eng_sig:       # iteration 0 has its own budgets; afterwards the engine is kept
+            if self._eng is not None:
+                self._eng.close()
+            kw = dict(device=c.device, concurrent_games=sig[0], num_traversals=sig[1], max_batch=sig[2], max_queue=sig[3],
+                      seed=c.seed, stream_base=self.next_stream)
+            self._eng = E.Engine(E.default_config(ENGINE_GAME[c.game], self.lib, **kw), self.lib)
+            self._eng_sig = sig
         self.next_stream += games
-        return E.Engine(E.default_config(ENGINE_GAME[c.game], self.lib, **kw), self.lib), games
+        return self._eng, games
 
     def self_play(self, iteration):
         eng, games = self._engine(iteration)
-        if self.model_path is None:
+        if self.traced is None:
             eng.set_model("random")                 # GridWorker.hpp:125-127
         elif self.forward_factory is not None:
             eng.set_forward(self.forward_factory(self.net))
         else:
-            eng.set_model(self.model_path)          # hot swap: no polling for the file
-        rec = eng.run(games)
-        states, dists, outcomes = rec.expand()
+            eng.set_model_module(self.traced)       # hot swap through memory: no file, no polling
+        eng.begin(games)
+        done = 0
+        while done < games:
+            done, _ = eng.step(64)
+        _, samples, _ = eng.records_info()
+        rows, cols, actions, hist = GAME_SHAPES[self.cfg.game]
+        # the engine's "device" is the GPU for the product library, host memory for the CPU emulator build used in tests
+        dev = torch.device(self.train_device) if self.lib.sprl_device_available() and torch.cuda.is_available() and \
+            getattr(self.lib, "_name", "").endswith("libsprl_amd.so") else torch.device("cpu")
+        states = torch.empty((samples, 2 * hist + 1, rows, cols), dtype=torch.float32, device=dev)
+        dists = torch.empty((samples, actions), dtype=torch.float32, device=dev)
+        outcomes = torch.empty((samples,), dtype=torch.float32, device=dev)
+        eng.expand_records_into(states.data_ptr(), dists.data_ptr(), outcomes.data_ptr(), samples)
         if self.cfg.write_files:
+            rec = eng.collect()
             d = os.path.join(self.root, "data", "games", self.cfg.run_name, "0", "0")
             os.makedirs(d, exist_ok=True)
             rec.write_npy(os.path.join(d, f"{self.cfg.run_name}_iteration_{iteration}"))
-        stats = eng.stats()
-        rec.close()
-        eng.close()
+            rec.close()
+        else:
+            eng.finish()
+        stats = dict(eng.stats(), games=games)      # (a kept engine's counters run on across iterations)
         return states, dists, outcomes, stats
 
     def step(self, iteration):
@@ -101,6 +123,7 @@ class SelfPlayTrainLoop:
         self.model_path = os.path.join(self.root, "data", "models", self.cfg.run_name,
                                        f"traced_{self.cfg.run_name}_iteration_{iteration}.pt")
         T.export_best(self.net, best, self.cfg.game, self.model_path)
+        self.traced = torch.jit.load(self.model_path, map_location="cpu") if self.forward_factory is None else True
         rec = dict(iteration=iteration, samples=int(states.shape[0]), games=stats["games"], lr=lr,
                    best_epoch=hist["best_epoch"], best_val=hist["best_val"], model=self.model_path)
         self.history.append(rec)
@@ -111,4 +134,10 @@ class SelfPlayTrainLoop:
     def run(self):
         for it in range(self.cfg.num_iters):
             self.step(it)
+        self.close()
         return self.history
+
+    def close(self):
+        if self._eng is not None:
+            self._eng.close()
+            self._eng = None

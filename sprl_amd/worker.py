@@ -1,4 +1,5 @@
-"""GPU self-play worker honouring the reference workers' process + filesystem contract.
+"""GPU self-play worker honouring the reference workers' process + filesystem contract - the Python face (ctypes) of the
+native worker `sprl_amd/sprl_worker` (sprl_amd/csrc/worker_main.cpp), same options and file layout.
 
 Mirrors `OTHWorker <task_id> <num_tasks>` / `C4Worker` (cpp/src/OTHWorker.cpp:31-70, cpp/src/C4Worker.cpp) and
 `runWorker` (cpp/src/selfplay/GridWorker.hpp:84-198):
@@ -20,8 +21,6 @@ import os
 import sys
 import time
 from dataclasses import dataclass
-
-import numpy as np
 
 from . import engine as E
 
@@ -53,6 +52,9 @@ REFERENCE_WORKERS = {
     "connect_four": WorkerConstants("connect_four", "c4_test", 1, 1, 25, 10, 2048, 1, 1, 5, 512, 8, 4, 0.25, 0.5),
     # GoWorker.cpp:11-29 (Go as compiled by the reference: 7x7)
     "go7": WorkerConstants("go7", "panda_alpha", 4, 384, 100, 3, 262144, 1, 1, 3, 32768, 16, 8, 0.25, 0.2),
+    # BASELINE configs 4 / 5: the Go worker's constants at 9x9 / 19x19 with 1600 iterations per move (the reference compiles 7x7 only)
+    "go9": WorkerConstants("go9", "panda_9x9", 4, 384, 100, 3, 1600, 16, 8, 3, 1600, 16, 8, 0.25, 0.2),
+    "go19": WorkerConstants("go19", "panda_19x19", 4, 384, 100, 3, 1600, 16, 8, 3, 1600, 16, 8, 0.25, 0.2),
 }
 
 
@@ -79,39 +81,25 @@ def save_dir_for(consts, task_id, root="."):
     return os.path.join(root, "data", "games", consts.run_name, str(group), str(task_id))
 
 
-def split_records(rec, games_per_task):
-    """Slice a run's compact records into per-task (states, distributions, outcomes) in the reference's sample order."""
-    states, dists, outs = rec.expand()
-    nsym = rec.nsym if rec.use_symmetry else 1
-    offs = rec.ply_offset.astype(np.int64) * nsym
-    out = []
-    for t in range(rec.num_games // games_per_task):
-        a, b = offs[t * games_per_task], offs[(t + 1) * games_per_task]
-        out.append((states[a:b], dists[a:b], outs[a:b]))
-    return out
-
-
-def _write_npy_atomic(path, arr):
-    tmp = path + ".tmp"
-    with open(tmp, "wb") as f:
-        _write_npy_reference_header(f, arr)
-    os.replace(tmp, path)
-
-
-def _write_npy_reference_header(f, arr):
-    """utils/npy.hpp:430-476 byte-for-byte (numpy's own writer pads differently)."""
-    arr = np.ascontiguousarray(arr, np.float32)
-    shape = "(%d,)" % arr.shape[0] if arr.ndim == 1 else "(" + ", ".join(str(s) for s in arr.shape) + ")"
-    d = "{'descr': '<f4', 'fortran_order': False, 'shape': %s, }" % shape
-    length = 6 + 2 + 2 + len(d) + 1
-    pad = 16 - length % 16
-    hl = len(d) + pad + 1
-    f.write(b"\x93NUMPY\x01\x00" + bytes([hl & 0xFF, hl >> 8]) + d.encode() + b" " * pad + b"\n")
-    f.write(arr.tobytes())
+def write_task_files(lib, rec, games_per_task, dirs, run_name, iteration, fmt="v1"):
+    """Each covered task's games go to that task's directory through the C ABI's own writers (sprl_records_slice +
+    sprl_write_npy: the reference's header bytes, temp file + rename, outcomes last; or the compact v2 file)."""
+    import ctypes as C
+    for k, d in enumerate(dirs):
+        part = E.Records()
+        rc = lib.sprl_records_slice(C.byref(rec._rec), k * games_per_task, games_per_task, C.byref(part))
+        if rc:
+            raise E.SprlError(rc, lib.sprl_last_error().decode())
+        prefix = os.path.join(d, f"{run_name}_iteration_{iteration}")
+        rc = lib.sprl_write_v2(os.fsencode(prefix + ".sprl2"), C.byref(part)) if fmt == "v2" else \
+            lib.sprl_write_npy(os.fsencode(prefix), C.byref(part))
+        lib.sprl_records_free(C.byref(part))
+        if rc:
+            raise E.SprlError(rc, lib.sprl_last_error().decode())
 
 
 def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, concurrent_games=None, lib=None,
-               model_for_iteration=None, log=print, device=0, resign_threshold=0.0, resign_min_ply=0):
+               model_for_iteration=None, log=print, device=0, resign_threshold=0.0, resign_min_ply=0, fmt="v1"):
     """The worker loop (GridWorker.hpp:111-197) for task ids [task_id, task_id + cover)."""
     lib = lib or E.load_library()
     num_iters = consts.num_iters if num_iters is None else num_iters
@@ -122,6 +110,7 @@ def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, co
         os.makedirs(d, exist_ok=True)
         log(("Directory already exists: " if existed else "Created directory: ") + d)
     next_stream = 1
+    eng, eng_sig = None, None
     for it in range(num_iters):
         log(f"Starting iteration {it}...")
         model = (model_for_iteration(it) if model_for_iteration else wait_model_path(it - 1, consts.run_name, root, log=log))
@@ -130,22 +119,22 @@ def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, co
         mb = consts.init_max_batch if it == 0 else consts.max_batch
         mq = consts.init_max_queue if it == 0 else consts.max_queue
         total = games * cover
-        cfg = E.default_config(consts.game, lib, device=device, concurrent_games=min(concurrent_games or total, total),
-                               num_traversals=trav, max_batch=mb, max_queue=mq, dir_eps=consts.dir_eps,
-                               dir_alpha=consts.dir_alpha, seed=seed, stream_base=next_stream,
-                               resign_threshold=resign_threshold, resign_min_ply=resign_min_ply)
-        next_stream += total
-        eng = E.Engine(cfg, lib)
+        sig = (trav, mb, mq, min(concurrent_games or total, total))
+        if eng is None or sig != eng_sig:          # one engine serves every steady-state iteration; only its model changes
+            if eng is not None:
+                eng.close()
+            cfg = E.default_config(consts.game, lib, device=device, concurrent_games=sig[3], num_traversals=trav, max_batch=mb,
+                                   max_queue=mq, dir_eps=consts.dir_eps, dir_alpha=consts.dir_alpha, seed=seed,
+                                   stream_base=next_stream, resign_threshold=resign_threshold, resign_min_ply=resign_min_ply)
+            eng, eng_sig = E.Engine(cfg, lib), sig
+        next_stream += total                        # (a kept engine continues its stream numbering itself)
         log("Using initial network..." if model == "random" else "Using traced PyTorch network...")
         eng.set_model(model)
         rec = eng.run(total)
-        for k, (st, di, ou) in enumerate(split_records(rec, games)):
-            prefix = os.path.join(dirs[k], f"{consts.run_name}_iteration_{it}")
-            _write_npy_atomic(prefix + "_states.npy", st)
-            _write_npy_atomic(prefix + "_distributions.npy", di)
-            _write_npy_atomic(prefix + "_outcomes.npy", ou)       # last: the controller waits for all three
+        write_task_files(lib, rec, games, dirs, consts.run_name, it, fmt)
         log(f"{total} games played, {rec.num_samples} states collected.")
         rec.close()
+    if eng is not None:
         eng.close()
 
 
@@ -163,6 +152,7 @@ def main(argv=None):
                     help="extension, not in the reference (default off): the side to move resigns when the mean value of its "
                          "decision node after the search is below -threshold")
     ap.add_argument("--resign-min-ply", type=int, default=0)
+    ap.add_argument("--format", default="v1", choices=["v1", "v2"], help="v1 = the reference's .npy triple; v2 = compact .sprl2")
     try:
         args = ap.parse_args(argv)
     except SystemExit:
@@ -176,7 +166,7 @@ def main(argv=None):
         consts = WorkerConstants(**{**consts.__dict__, "run_name": args.run_name})
     print(f"Task {args.task_id} of {args.num_tasks}, covering {args.cover} task(s).")
     run_worker(consts, args.task_id, cover=args.cover, num_iters=args.num_iters, device=args.device, seed=args.seed,
-               resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
+               resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply, fmt=args.format)
     return 0
 
 

@@ -75,3 +75,90 @@ def test_product_never_references_oracle():
             if f.endswith((".py", ".h", ".cpp", ".hip", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "pyoracle" not in text and "sprl_oracle" not in text, f
+
+
+def _struct_fields(text, name):
+    """Field names of `typedef struct name { ... } name;` in the header, in declaration order."""
+    body = re.search(r"typedef struct " + name + r"\s*\{(.*?)\}\s*" + name + r"\s*;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = re.findall(r"[A-Za-z_][A-Za-z0-9_]*", names[0])[-1]
+        fields.append(first)
+        for extra in names[1:]:
+            fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", extra)[-1])
+    return fields
+
+
+def test_ctypes_mirror_matches_the_header_layout(tmp_path):
+    """the only consumer of include/sprl_amd.h used to be a hand-written ctypes mirror.  A C program
+    compiled against the header prints sizeof / offsetof of every field of every struct; the ctypes mirror must agree."""
+    text = open(os.path.join(ROOT, "include", "sprl_amd.h")).read()
+    mirror = {"sprl_config": E.Config, "sprl_records": E.Records, "sprl_stats": E.Stats, "sprl_match_agent": E.MatchAgent}
+    src = ['#include <stddef.h>', '#include <stdio.h>', '#include "sprl_amd.h"', "int main(void) {"]
+    for name in mirror:
+        src.append(f'    printf("{name} sizeof %zu\\n", sizeof({name}));')
+        for f in _struct_fields(text, name):
+            src.append(f'    printf("{name} {f} %zu\\n", offsetof({name}, {f}));')
+    src += ["    return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        name, field, value = line.split()
+        cls = mirror[name]
+        if field == "sizeof":
+            assert C.sizeof(cls) == int(value), (name, C.sizeof(cls), value)
+        else:
+            assert getattr(cls, field).offset == int(value), (name, field, getattr(cls, field).offset, value)
+        seen += 1
+    assert seen > 80
+    for name, cls in mirror.items():                       # and the mirror has no field the header lacks
+        assert [f[0] for f in cls._fields_] == _struct_fields(text, name), name
+
+
+def test_integration_md_snippets_compile(tmp_path):
+    """The reference-side bindings shown in INTEGRATION.md are real code: every ```cpp block is compiled (syntax + types)
+    against include/sprl_amd.h inside a function that declares the reference's local variables."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", md, flags=re.S)
+    assert len(blocks) >= 2
+    prologue = """
+#include <cstdint>
+#include <iostream>
+#include <random>
+#include <string>
+#include <type_traits>
+#include <vector>
+struct OthelloNode {}; struct ConnectFourNode {};
+"""
+    for i, body in enumerate(blocks):
+        includes = "\n".join(l for l in body.splitlines() if l.startswith(("extern", "#include", "}")) and "{" not in l.replace('extern "C" {', ""))
+        code = "\n".join(l for l in body.splitlines() if not (l.startswith(("extern", "#include")) or l.strip() == "}"))
+        src = prologue + 'extern "C" {\n#include "sprl_amd.h"\n}\n' + f"""
+template <class ImplNode>
+int snippet_{i}(int numGames, int numTraversals, int maxBatchSize, int maxQueueSize, float dirEps, float dirAlpha, int iter,
+              std::string modelPath, std::string savePath, std::string modelPath0, std::string modelPath1,
+              int model0UseSymmetrize, int model0UseParentQ, int model1UseSymmetrize, int model1UseParentQ) {{
+    int numWins0 = 0, numWins1 = 0;
+#define return return 0 +
+{code}
+#undef return
+    return numWins0 + numWins1;
+}}
+template int snippet_{i}<OthelloNode>(int, int, int, int, float, float, int, std::string, std::string, std::string, std::string, int, int, int, int);
+"""
+        # `return;` inside the snippets (void context in the reference) becomes `return 0 + ;`: make that legal
+        src = src.replace("return;", "return 0;").replace("return 1;", "return 1;")
+        src = src.replace("#define return return 0 +\n", "").replace("#undef return\n", "")
+        f = tmp_path / f"snippet_{i}.cpp"
+        f.write_text(src)
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-variable",
+                               "-I", os.path.join(ROOT, "include"), str(f)])

@@ -123,14 +123,18 @@ def test_go9_two_strip_rows(emu):
     """Go 9x9 (BASELINE config 4 geometry): 81 points + pass = rows of two wavefront strips, 2-word bit boards."""
     rec, st = parity.check_case(emu, "go9", 2, concurrent_games=2, num_traversals=40)
     assert rec.cells == 81 and rec.actions == 82 and rec.planes == 17
-    rec, st = parity.check_case(emu, "go9", 2, concurrent_games=2, num_traversals=60, node_cap=200, spare_arenas=2, seed=9)
-    assert st["compactions"] > 0
+    rec, st = parity.check_case(emu, "go9", 2, concurrent_games=2, num_traversals=60, node_cap=200, spare_arenas=2, seed=9,
+                                no_recycle=1)
+    assert st["compactions"] > 0 and st["nodes_recycled"] == 0
+    # the same games with node recycling (the default): the 200-node arenas are never compacted
+    rec, st = parity.check_case(emu, "go9", 2, concurrent_games=2, num_traversals=60, node_cap=200, spare_arenas=0, seed=9)
+    assert st["compactions"] == 0 and st["nodes_recycled"] > 0.5 * st["nodes_created"] and st["max_nodes_in_arena"] <= 200
 
 
 def test_go19_six_strip_rows(emu):
     """Go 19x19 (BASELINE config 5 geometry): 361 points + pass, rows of six strips, 6-word bit boards."""
     rec, st = parity.check_case(emu, "go19", 1, concurrent_games=1, num_traversals=12, seed=4)
-    assert rec.cells == 361 and rec.actions == 362
+    assert rec.cells == 361 and rec.actions == 362 and st["nodes_recycled"] > 0
 
 
 def test_go9_network_path_toy_forward(emu):

@@ -1,6 +1,7 @@
 """The hand-written trunk convolution (sprl_amd/csrc/cnn_wino.hip: Winograd F(4x4,3x3) on fp32 MFMA with fused
-scale/shift/residual/ReLU) against PyTorch's fp32 conv2d on the same inputs.  Tolerance: 2e-4 absolute on outputs of
-magnitude O(1-10) — F(4x4,3x3) in fp32 carries ~1e-5 relative error through its transforms."""
+scale/shift/residual/ReLU) against a float64 conv2d on the same inputs.  Tolerance: 8e-5 absolute on outputs of magnitude
+O(1-10) with N(0,1) inputs in all 64 channels - twice the 3.7e-5 measured by tools/wino_lab.hip on 14 400 such boards
+(F(4x4,3x3) in fp32 carries ~1e-5 relative error through its transforms); real network activations: tests/test_gpu_parity.py."""
 import ctypes as C
 import os
 
@@ -75,7 +76,7 @@ def test_wino_conv_matches_conv2d(plug, H, W, B):
             want = torch.relu(want)
         got = run_conv(plug, x, w, scale, shift, res if use_res else None, relu)
         err = (got.double() - want).abs().max().item()
-        assert err < 2e-4, (H, W, B, use_res, relu, err)
+        assert err < 8e-5, (H, W, B, use_res, relu, err)
 
 
 def test_wino_structured_inputs(plug):
@@ -119,4 +120,4 @@ def test_wino_conv_general_boards_nchw(plug, H, W, B):
         assert rc == 0
         torch.cuda.synchronize()
         err = (y.double() - want).abs().max().item()
-        assert err < 2e-4, (H, W, B, use_res, relu, err)
+        assert err < 8e-5, (H, W, B, use_res, relu, err)
