@@ -137,8 +137,11 @@ GAMES = {
                 label="Go 7x7", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=8, board_bytes=49),
     "go9": dict(engine="go9", rows=9, cols=9, A=82, planes=17, concurrent=1024, traversals=1600, blocks=6, bq="16/8",
                 label="Go 9x9", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=11, board_bytes=81),
+    # config 5 names a resign threshold: on by default for this game (with random-init weights the decision is noise and games
+    # end after ~min-ply moves; without it every game runs to the 722-ply cap, ~20 min per step)
     "go19": dict(engine="go19", rows=19, cols=19, A=362, planes=17, concurrent=256, traversals=1600, blocks=6, bq="16/8",
-                 label="Go 19x19", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=46, board_bytes=361),
+                 label="Go 19x19", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=46, board_bytes=361,
+                 resign_threshold=0.05, resign_min_ply=60),
 }
 
 
@@ -160,8 +163,9 @@ def main():
     ap.add_argument("--populations", type=int, default=1,
                     help="split the resident games of a GPU into this many engines, each on its own HIP stream and host thread: "
                          "one population's tree kernel and convolution tails overlap the other's CNN work")
-    ap.add_argument("--resign-threshold", type=float, default=0.0, help="extension (BASELINE config 5), 0 = off as in the reference")
-    ap.add_argument("--resign-min-ply", type=int, default=0)
+    ap.add_argument("--resign-threshold", type=float, default=-1.0,
+                    help="extension (BASELINE config 5), 0 = off as in the reference (default: off, go19: 0.05)")
+    ap.add_argument("--resign-min-ply", type=int, default=-1, help="default 0 (go19: 60)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
@@ -174,6 +178,10 @@ def main():
     args.concurrent = args.concurrent or G["concurrent"]
     args.traversals = args.traversals or G["traversals"]
     args.blocks = args.blocks or G["blocks"]
+    if args.resign_threshold < 0:
+        args.resign_threshold = G.get("resign_threshold", 0.0)
+    if args.resign_min_ply < 0:
+        args.resign_min_ply = G.get("resign_min_ply", 0)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -295,6 +303,7 @@ def main():
         return tot
 
     st0 = all_stats()
+    lib.sprl_profile_busy_reset()
     gather_s[0] = 0.0
     barrier()
     t0 = time.perf_counter()
@@ -308,6 +317,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st1 = all_stats()
+    # several populations: launches of one kernel overlap on different streams; busy = time with >= 1 launch executing
+    tree_busy, tree_sum = E.profile_busy(lib, 0)
+    conv_busy, conv_sum = E.profile_busy(lib, 1) if model_path else (None, None)
     d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
 
     if rank == 0:
@@ -354,10 +366,14 @@ def main():
             out["phase_cycles_share"]["per_level_cycles"] = {k: d["cyc_lvl_" + k] / max(1, d["levels"]) for k in ("wait", "pick", "desc")}
             out["phase_cycles_share"]["total_cycles_per_slot_launch"] = d["cyc_total"] / max(1, d["kernel_launches"]) / args.concurrent
         if not args.no_profile and d["kernel_ms"] > 0:
-            achieved = d["traversals"] * bpt / (d["kernel_ms"] * 1e-3) / 1e9
+            # achieved = algorithmic bytes of all launches / time the kernel was executing.  One engine: that time is the sum
+            # of the launch durations (= launches x avg_launch_ms).  Several engines (--populations): their launches overlap on
+            # different HIP streams, the time is the union of the launch intervals (sprl_profile_busy), from the same events.
+            tree_time_ms = tree_busy if (pops > 1 and tree_busy) else d["kernel_ms"]
+            achieved = d["traversals"] * bpt / (tree_time_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "tree_kernel_traffic.json")
-            if os.path.exists(tpath):           # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
+            if os.path.exists(tpath) and args.game == "othello":   # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
                 with open(tpath) as tf:
                     traffic = json.load(tf).get("hbm_bytes_per_launch")
             tree = {"bound": "hbm", "kernel": f"step_kernel ({G['label']}: select/expand/backup/re-root)",
@@ -365,7 +381,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "bytes_per_traversal": bpt,
                     "avg_launch_ms": d["kernel_ms"] / max(1, d["kernel_launches"]),
-                    "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"])}
+                    "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"]),
+                    "launch_ms_sum": d["kernel_ms"], "busy_ms": tree_busy,
+                    "overlap": (tree_sum / tree_busy) if tree_busy else None}
             if d.get("conv_ms", 0) > 0:
                 # the dominant kernel by time: the trunk convolution of the CNN (cnn_wino.hip), fp32 MFMA-bound.
                 # Algorithmic work per board and launch = the Winograd-domain products the kernel must issue:
@@ -373,7 +391,8 @@ def main():
                 tiles = ((G["rows"] + 3) // 4) * ((G["cols"] + 3) // 4)
                 flop_per_board = 2 * tiles * 36 * 64 * 64
                 flop = d["conv_boards"] * flop_per_board
-                tf = flop / (d["conv_ms"] * 1e-3) / 1e12
+                conv_time_ms = conv_busy if (pops > 1 and conv_busy) else d["conv_ms"]
+                tf = flop / (conv_time_ms * 1e-3) / 1e12
                 ctraffic = None
                 cpath = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
                 if os.path.exists(cpath):
@@ -381,7 +400,9 @@ def main():
                         ctraffic = json.load(tf_).get("hbm_bytes_per_launch")
                 out["roofline"] = {"bound": "mfma", "kernel": "wino_conv64 (3x3 conv 64->64 + BN/residual/ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
                                    "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                                   "traffic": ctraffic, "share_of_step_time": d["conv_ms"] * 1e-3 / elapsed,
+                                   "traffic": ctraffic, "share_of_step_time": conv_time_ms * 1e-3 / elapsed,
+                                   "launch_ms_sum": d["conv_ms"], "busy_ms": conv_busy,
+                                   "overlap": (conv_sum / conv_busy) if conv_busy else None,
                                    "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
                                    "boards_per_launch": d["conv_boards"] / max(1, d["conv_launches"]),
                                    "flop_per_board": flop_per_board,

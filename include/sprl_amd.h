@@ -181,6 +181,14 @@ typedef struct sprl_stats {
 } sprl_stats;
 int sprl_engine_stats(sprl_engine* e, sprl_stats* out);
 
+/* profile=1, several engines in one process (one HIP stream each): launches of the same kernel overlap in time, so the sum of
+ * their durations (sprl_stats.kernel_ms / conv_ms) no longer says how long the device spent on them.  busy_ms = the time since
+ * sprl_profile_busy_reset() during which at least one launch of the kind was executing, over ALL engines of the process, from
+ * the same HIP events; sum_ms = the sum of the durations.  kind 0 = tree kernel, 1 = trunk convolution of the network plugin.
+ * Call sprl_engine_stats on every engine first (it resolves the pending events).  With one engine busy_ms == sum_ms. */
+int sprl_profile_busy(int kind, double* busy_ms, double* sum_ms);
+void sprl_profile_busy_reset(void);
+
 /* Expanded training samples exactly as the reference worker emits them (selfplay/GridWorker.hpp:146-196):
  * states float32[N][2H+1][R][C], distributions float32[N][A], outcomes float32[N], N = plies * nsym.
  * Buffers are caller-provided (sizes from sprl_records_num_samples). */

@@ -43,6 +43,13 @@ int launch_records_expand(int game, const EngineParams& P, const RecExpanded& ou
 void* mark();
 double elapsed_ms(void* a, void* b);   // synchronises on b
 void mark_free(void* m);
+// profile mode, tree kernel: the pair's duration (synchronises on b), the interval also logged on the process-wide clock of
+// busy_log.h (all engines of the process: bench.py --populations); both marks are consumed.  `chain` from chain_new().
+void* chain_new();
+void chain_free(void* chain);
+double resolve_logged(void* chain, void* a, void* b);
+double busy_ms(double* sum_ms);     // time with >= 1 tree kernel executing since busy_reset(); sum_ms = sum of the durations
+void busy_reset();
 const char* name();
 const char* last_error();
 }  // namespace be

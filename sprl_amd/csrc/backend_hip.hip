@@ -3,6 +3,7 @@
 
 #include <string>
 
+#include "busy_log.h"
 #include "backend.h"
 #include "records_kernel.h"
 #include "step_kernel.h"
@@ -271,6 +272,24 @@ double elapsed_ms(void* a, void* b) {
 void mark_free(void* m) {
     if (m) (void)hipEventDestroy((hipEvent_t)m);
 }
+
+static busy::Log g_tree_busy;
+void* chain_new() { return new busy::Chain(); }
+void chain_free(void* chain) {
+    if (!chain) return;
+    static_cast<busy::Chain*>(chain)->release();
+    delete static_cast<busy::Chain*>(chain);
+}
+double resolve_logged(void* chain, void* a, void* b) {
+    double ms = 0.0;
+    (void)hipEventSynchronize((hipEvent_t)b);
+    const auto iv = static_cast<busy::Chain*>(chain)->resolve((hipEvent_t)a, (hipEvent_t)b, &ms);
+    (void)hipEventDestroy((hipEvent_t)b);
+    g_tree_busy.add(iv);
+    return ms;
+}
+double busy_ms(double* sum_ms) { return g_tree_busy.union_ms(sum_ms); }
+void busy_reset() { g_tree_busy.reset(); }
 
 const char* last_error() { return g_err.c_str(); }
 }  // namespace be

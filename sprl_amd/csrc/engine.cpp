@@ -122,6 +122,7 @@ struct sprl_engine {
     int64_t rec_total = -1;     // total plies of the finished run once the device-side offsets scan has run, else -1
     std::vector<void*> marks;  // k0,k1,(n0,n1) per round, resolved lazily
     std::vector<int> mark_kind;
+    void* chain = nullptr;     // be::chain_new(): this engine's tree-kernel intervals on the process-wide busy clock
 };
 
 namespace {
@@ -135,11 +136,18 @@ void* dev_alloc(sprl_engine* e, size_t bytes) {
     return p;
 }
 
+// trunk-convolution busy clock of the evaluator plugin (one per process)
+double (*g_conv_busy)(double*) = nullptr;
+void (*g_conv_busy_reset)() = nullptr;
+
 void resolve_marks(sprl_engine* e) {
     for (size_t i = 0; i + 1 < e->marks.size(); i += 2) {
-        double ms = be::elapsed_ms(e->marks[i], e->marks[i + 1]);
-        if (e->mark_kind[i / 2] == 0) e->kernel_ms += ms;
-        else e->nn_ms += ms;
+        if (e->mark_kind[i / 2] == 0) {          // tree kernel: also on the process-wide busy clock (several engines overlap)
+            if (!e->chain) e->chain = be::chain_new();
+            e->kernel_ms += be::resolve_logged(e->chain, e->marks[i], e->marks[i + 1]);
+            continue;
+        }
+        e->nn_ms += be::elapsed_ms(e->marks[i], e->marks[i + 1]);
         be::mark_free(e->marks[i]);
         be::mark_free(e->marks[i + 1]);
     }
@@ -169,6 +177,8 @@ int load_torch_plugin(sprl_engine* e) {
         lib, "sprl_torch_forward_dev");
     e->torch.profile_enable = (void (*)(void*, int))dlsym(lib, "sprl_torch_profile_enable");
     e->torch.profile_read = (void (*)(void*, double*, int64_t*, int64_t*))dlsym(lib, "sprl_torch_profile_read");
+    g_conv_busy = (double (*)(double*))dlsym(lib, "sprl_torch_profile_busy");
+    g_conv_busy_reset = (void (*)())dlsym(lib, "sprl_torch_profile_busy_reset");
     if (!e->torch.load || !e->torch.forward || !e->torch.release)
         return fail(SPRL_E_MODEL, "LibTorch evaluator plugin lacks required symbols");
     return 0;
@@ -406,6 +416,7 @@ void sprl_engine_destroy(sprl_engine* e) {
     be::bind(e->cfg.device, e->stream);
     be::sync();
     resolve_marks(e);
+    be::chain_free(e->chain);
     if (e->torch_model && e->torch.release) e->torch.release(e->torch_model);
     for (void* p : e->allocs) be::dfree(p);
     if (e->stream) be::stream_destroy(e->stream);
@@ -470,7 +481,7 @@ int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len) {
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2 && e->g.rows <= 8 && e->g.cols <= 8)
                            ? "hand-written gfx950 CNN: MFMA stem + Winograd F(4x4,3x3) fp32-MFMA trunk with fused BN/residual/ReLU + fused heads/FC tail"
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2)
-                           ? "library stem convolution + hand-written Winograd F(4x4,3x3) fp32-MFMA trunk (any board size) + fused heads kernel"
+                           ? "hand-written gfx950 CNN for any board: NCHW stem kernel + Winograd F(4x4,3x3) fp32-MFMA trunk + 1x1 heads kernel, rocBLAS FC tail"
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model))
                            ? "LibTorch-ROCm: MIOpen convolutions + fused bias/BN/ReLU epilogue kernel"
                            : "LibTorch-ROCm: TorchScript graph (bias hoisted for the JIT fuser)";
@@ -970,6 +981,21 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out) {
             out->conv_boards = (int64_t)((double)e->nn_rows * (double)out->conv_launches / (double)e->nn_batches);
     }
     return 0;
+}
+
+int sprl_profile_busy(int kind, double* busy_ms, double* sum_ms) {
+    double sum = 0.0, busy = 0.0;
+    if (kind == 0) busy = be::busy_ms(&sum);
+    else if (kind == 1 && g_conv_busy) busy = g_conv_busy(&sum);
+    else return fail(SPRL_E_CONFIG, "sprl_profile_busy: kind 0 = tree kernel, 1 = trunk convolution (needs a loaded network)");
+    if (busy_ms) *busy_ms = busy;
+    if (sum_ms) *sum_ms = sum;
+    return 0;
+}
+
+void sprl_profile_busy_reset(void) {
+    be::busy_reset();
+    if (g_conv_busy_reset) g_conv_busy_reset();
 }
 
 // ---------------------------------------------------------------------------------------------------------

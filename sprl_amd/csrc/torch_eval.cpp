@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 
+#include "busy_log.h"
+
 extern "C" int sprl_bn_relu_inplace(float* x, const float* residual, const float* scale, const float* shift,
                                     int64_t numel, int channels, int hw, void* stream);
 extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,
@@ -59,21 +61,30 @@ struct NativeNet {
 };
 
 // live timing of the trunk convolution kernel (profile mode): HIP event pairs on the stream the kernel is launched on
+busy::Log g_conv_busy;
+
 struct ConvProfile {
     bool on = false;
     std::vector<hipEvent_t> ev;          // pairs, resolved lazily
     double ms = 0.0;
     int64_t launches = 0, boards = 0;
+    busy::Chain chain;                   // the same intervals on the process-wide clock (several models on several streams)
     void resolve() {
+        std::vector<std::pair<double, double>> iv;
+        iv.reserve(ev.size() / 2);
         for (size_t i = 0; i + 1 < ev.size(); i += 2) {
-            float t = 0.0f;
+            double t = 0.0;
             (void)hipEventSynchronize(ev[i + 1]);
-            (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+            iv.push_back(chain.resolve(ev[i], ev[i + 1], &t));
             ms += t;
-            (void)hipEventDestroy(ev[i]);
             (void)hipEventDestroy(ev[i + 1]);
         }
         ev.clear();
+        g_conv_busy.add(iv);
+    }
+    ~ConvProfile() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        chain.release();
     }
 };
 
@@ -451,6 +462,9 @@ void sprl_wino_transform_weights(const float* w, float* u) { wino_transform(w, u
 
 // profile mode: time every trunk-convolution launch with HIP events; totals since load (ms, launches, boards)
 void sprl_torch_profile_enable(void* handle, int on) { static_cast<Model*>(handle)->prof.on = on != 0; }
+// time with >= 1 trunk-convolution launch executing, over all models of the process (busy_log.h); read after profile_read
+double sprl_torch_profile_busy(double* sum_ms) { return g_conv_busy.union_ms(sum_ms); }
+void sprl_torch_profile_busy_reset() { g_conv_busy.reset(); }
 void sprl_torch_profile_read(void* handle, double* conv_ms, int64_t* launches, int64_t* boards) {
     ConvProfile& p = static_cast<Model*>(handle)->prof;
     p.resolve();

@@ -117,6 +117,8 @@ def load_library(path=None):
     L.sprl_engine_pack_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.sprl_engine_expand_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.sprl_engine_finish.argtypes = [C.c_void_p]
+    L.sprl_profile_busy.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.sprl_profile_busy_reset.restype = None
     L.sprl_records_free.argtypes = [C.POINTER(Records)]
     L.sprl_records_free.restype = None
     L.sprl_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -347,3 +349,11 @@ def match_score(winners):
     a0 = int(np.sum((w >= 0) & ((w ^ (g & 1)) == 0)))
     a1 = int(np.sum((w >= 0) & ((w ^ (g & 1)) == 1)))
     return a0, a1, int(np.sum(w < 0))
+
+
+def profile_busy(lib, kind):
+    """(busy_ms, sum_ms) of sprl_profile_busy: kind 0 = tree kernel, 1 = trunk convolution; (None, None) when unavailable."""
+    busy, total = C.c_double(0.0), C.c_double(0.0)
+    if lib.sprl_profile_busy(kind, C.byref(busy), C.byref(total)) != 0:
+        return None, None
+    return busy.value, total.value

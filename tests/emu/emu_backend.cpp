@@ -134,4 +134,19 @@ double elapsed_ms(void* a, void* b) {
     return std::chrono::duration<double, std::milli>(*tb - *ta).count();
 }
 void mark_free(void* m) { delete (std::chrono::steady_clock::time_point*)m; }
+static double g_busy_sum = 0.0;                 // the emulator runs one kernel at a time: busy time = sum of the durations
+void* chain_new() { return nullptr; }
+void chain_free(void*) {}
+double resolve_logged(void*, void* a, void* b) {
+    const double ms = elapsed_ms(a, b);
+    mark_free(a);
+    mark_free(b);
+    g_busy_sum += ms;
+    return ms;
+}
+double busy_ms(double* sum_ms) {
+    if (sum_ms) *sum_ms = g_busy_sum;
+    return g_busy_sum;
+}
+void busy_reset() { g_busy_sum = 0.0; }
 }  // namespace be

@@ -1,6 +1,12 @@
 // Experiment bench for the trunk convolution (diagnostic, never shipped): variants of the Winograd/MFMA kernel timed in
 // interleaved rounds in ONE process on random data, each checked against a float64 direct convolution on the host.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/wino_lab tools/wino_lab.hip && tools/wino_lab [boards] [rounds]
+// the variants file carries its own copies of the product's entry points: rename them, the real ones are linked in
+#define sprl_wino_weight_layout var_wino_weight_layout
+#define sprl_wino_conv64_dev var_wino_conv64_dev
+#define sprl_wino_conv64_heads var_wino_conv64_heads
+#define sprl_wino_conv64_nchw var_wino_conv64_nchw
+#define sprl_wino_conv64 var_wino_conv64
 #include "wino_variants.hip"   // the experimental variants (v2 = round-1 kernel, v4 = flag-switched experiments); the product kernel
                                // (sprl_amd/csrc/cnn_wino.hip) is variant v4<8192>: filters as U36 through a register ring
 
@@ -11,6 +17,14 @@
 #include <vector>
 
 namespace {
+
+#undef sprl_wino_weight_layout
+#undef sprl_wino_conv64_dev
+#undef sprl_wino_conv64_heads
+#undef sprl_wino_conv64_nchw
+#undef sprl_wino_conv64
+extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y,
+                                int batch, int H, int W, int relu, void* stream);
 
 struct Variant {
     const char* name;
@@ -141,7 +155,14 @@ int main(int argc, char** argv) {
     hipMemcpy(sh, hsh.data(), 256, hipMemcpyHostToDevice);
     g_u36 = u; g_g9 = g9;
 
+    // the product kernel itself (sprl_amd/csrc/cnn_wino.hip compiled into this binary).  A persistent form of it (grid = resident
+    // workgroups, next group's first chunks and filter quads requested in the second half of the output stage) was measured here
+    // in round 2 and dropped: 328 us against 219 us at 13 492 boards (profiles/r02d_wino_lab_persistent.log) - the two
+    // workgroups of a CU start together and stay in phase, so the output stage of one no longer overlaps the MFMA phases of the
+    // other, and keeping the per-lane indices alive over the group loop spills ~130 registers.
     std::vector<Variant> vs = {
+        { "PRODUCT cnn_wino.hip", [](const float* x, const float* w, const float* sc, const float* sh, const float* r, float* y, int B) {
+             sprl_wino_conv64(x, w, sc, sh, r, y, B, 8, 8, 1, nullptr); }, 0 },
         { "v2 product (U36 from L2)", launch_v2, 0 },
         { "v4 G9 scaled + row-ahead U + b128", launch_v4<8 + 16 + 2048>, 1 },
         { "v4 U36' ring (scaled), b32 V", launch_v4<16 + 8192>, 2 },
