@@ -337,10 +337,97 @@ __global__ void __launch_bounds__(256) stem_nchw_kernel(const float* __restrict_
     }
 }
 
+// The same stem on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), any board and plane count: out[64 ch][cells] =
+// W[64][9 P] x patches[9 P][cells].  A wave takes 16 consecutive cells of the batch (board-major, so a store instruction
+// writes 64 contiguous bytes per channel) and all 64 channels.  K is ordered (plane group of 4, tap): in step s = 9 pg + t the
+// four K slots are planes 4 pg .. 4 pg + 3 at tap t (planes >= P carry zero weights), so a lane's patch value sits at
+// tapoff[t] + planeoff[pg] - two small per-lane tables instead of one offset per step.  The patch values come straight from the
+// NCHW planes through a buffer descriptor (off-board taps and missing planes get offsets past the tensor, which read as 0); the
+// A fragments of all steps sit in LDS in lane order, one 16-byte read per step for the four channel blocks.
+// Go 9x9, 8192 boards x 17 planes: 0.84 ms (VALU form above) -> see DESIGN.md section 5.
+template <int P>
+__global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __restrict__ planes, const float* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             float* __restrict__ y, long long cells, int H, int W) {
+    constexpr int PG = (P + 3) / 4, KS = PG * 9;
+    __shared__ __attribute__((aligned(16))) float wsh[KS * 64 * 4];          // [step][lane][channel block]
+    __shared__ float scsh[2][64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qs = lane >> 4, l16 = lane & 15;
+    for (int e = tid; e < KS * 64 * 4; e += 256) {
+        const int kb = e & 3, ln = (e >> 2) & 63, st = e >> 8;
+        const int plane = 4 * (st / 9) + (ln >> 4), tap = st % 9;
+        wsh[e] = plane < P ? w[((size_t)(16 * kb + (ln & 15)) * P + plane) * 9 + tap] : 0.0f;
+    }
+    if (tid < 64) {
+        scsh[0][tid] = scale[tid];
+        scsh[1][tid] = shift[tid];
+    }
+    __syncthreads();
+    const int HW = H * W;
+    const unsigned in_bytes = (unsigned)(cells * P * 4);                      // the host keeps this below 1 GiB
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)planes, 0, in_bytes, 0x00020000);
+    const long long tiles = (cells + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tiles; tile += (long long)gridDim.x * 4) {
+        const long long e = tile * 16 + l16;
+        const bool live = e < cells;
+        const int n = live ? (int)(e / HW) : 0, cell = live ? (int)(e % HW) : 0;
+        const int row = cell / W, col = cell % W;
+        int tapoff[9], pgoff[PG];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = row + t / 3 - 1, c = col + t % 3 - 1;
+            tapoff[t] = (live && r >= 0 && r < H && c >= 0 && c < W) ? (n * P * HW + r * W + c) * 4 : (int)0x80000000;
+        }
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) pgoff[pg] = 4 * pg + qs < P ? (4 * pg + qs) * HW * 4 : 0x40000000;
+        float b[KS];
+#pragma unroll
+        for (int st = 0; st < KS; ++st)
+            b[st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, tapoff[st % 9] + pgoff[st / 9], 0, 0));
+        stem_f4 acc[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc[kb] = (stem_f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+        stem_f4 a = *(const stem_f4*)&wsh[lane * 4];
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            // the next step's fragments are requested before this step's MFMAs and nothing moves across the barrier: without it
+            // the scheduler hoists all KS reads (4 KS registers) to the top
+            const stem_f4 an = *(const stem_f4*)&wsh[((st + 1 < KS ? st + 1 : st) * 64 + lane) * 4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb], b[st], acc[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a = an;
+        }
+        // accumulator row r of block kb = channel 16 kb + 4 qs + r, column = this lane's cell
+        if (live) {
+            float* yo = y + ((size_t)n * 64) * HW + cell;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * kb + 4 * qs + r;
+                    const float v = acc[kb][r] * scsh[0][k] + scsh[1][k];
+                    yo[(size_t)k * HW] = v > 0.0f ? v : 0.0f;
+                }
+        }
+    }
+}
+
 extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                       long long batch, int P, int H, int W, void* stream) {
     if (batch <= 0) return 0;
     const long long cells = batch * H * W;
+    if (cells * P * 4 < 0x40000000LL && !getenv("SPRL_STEM_VALU")) {
+        long long blocks = (cells / 16 + 3) / 4;
+        if (blocks > 256 * 6) blocks = 256 * 6;        // grid-stride over 16-cell tiles: the weight fragments are staged once per workgroup
+        if (blocks < 1) blocks = 1;
+        const dim3 g((unsigned)blocks), bl(256);
+        if (P == 3) hipLaunchKernelGGL(stem_mfma_nchw_kernel<3>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W);
+        else if (P == 17) hipLaunchKernelGGL(stem_mfma_nchw_kernel<17>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W);
+        else return -1;
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const dim3 grid((unsigned)((cells + 255) / 256)), block(256);
     if (P == 3) hipLaunchKernelGGL(stem_nchw_kernel<3>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W);
     else if (P == 17) hipLaunchKernelGGL(stem_nchw_kernel<17>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W);

@@ -121,3 +121,30 @@ def test_wino_conv_general_boards_nchw(plug, H, W, B):
         torch.cuda.synchronize()
         err = (y.double() - want).abs().max().item()
         assert err < 8e-5, (H, W, B, use_res, relu, err)
+
+
+@pytest.mark.parametrize("P,H,W,B", [(17, 9, 9, 7), (17, 19, 19, 3), (3, 13, 6, 11), (17, 9, 9, 513), (3, 9, 9, 1)])
+def test_stem_any_board_mfma_and_valu_forms(plug, P, H, W, B):
+    """Stem for boards wider than 8 (cnn_epilogue.hip: stem_mfma_nchw_kernel on the matrix cores, and the VALU form behind
+    SPRL_STEM_VALU) against conv2d in float64: conv3x3 P -> 64, folded scale/shift, ReLU, NCHW in and out."""
+    import torch
+    plug.sprl_stem_conv3x3_nchw.argtypes = [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    torch.manual_seed(P * 100 + H + B)
+    x = (torch.rand(B, P, H, W, device="cuda") < 0.4).float() + 0.25 * torch.randn(B, P, H, W, device="cuda")
+    w = torch.randn(64, P, 3, 3, device="cuda") * 0.2
+    scale = torch.rand(64, device="cuda") + 0.5
+    shift = torch.randn(64, device="cuda") * 0.3
+    want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1)
+                      + shift.double().view(1, -1, 1, 1))
+    for valu in (False, True):
+        if valu:
+            os.environ["SPRL_STEM_VALU"] = "1"
+        try:
+            y = torch.full((B, 64, H, W), float("nan"), device="cuda")
+            rc = plug.sprl_stem_conv3x3_nchw(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, P, H, W, None)
+            assert rc == 0
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SPRL_STEM_VALU", None)
+        err = (y.double() - want).abs().max().item()
+        assert err < 1e-5, (P, H, W, B, valu, err)
