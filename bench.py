@@ -130,7 +130,7 @@ GAMES = {
     # game: engine name, board, actions, planes, default concurrent games, traversals, CNN blocks (the reference controllers'
     # MODEL_NUM_BLOCKS: othello/connect_four 2, go 6), batch/queue (worker constants), label
     "othello": dict(engine="othello", rows=8, cols=8, A=65, planes=3, concurrent=4096, traversals=800, blocks=2, bq="8/4",
-                    label="Othello 8x8", sym="D4", noise="Dirichlet(0.25,0.3)", mask_bytes=8, board_bytes=64),
+                    label="Othello 8x8", sym="D4", noise="Dirichlet(0.25,0.3)", mask_bytes=8, board_bytes=64, populations=2),
     "connect_four": dict(engine="connect_four", rows=6, cols=7, A=7, planes=3, concurrent=4096, traversals=100, blocks=2, bq="8/4",
                          label="Connect Four 6x7", sym="mirror", noise="Dirichlet(0.25,0.5)", mask_bytes=8, board_bytes=42),
     "go7": dict(engine="go7", rows=7, cols=7, A=50, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8",
@@ -160,9 +160,12 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="residual blocks of the CNN (default per game: othello 2, go 6)")
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--rounds-per-call", type=int, default=64)
-    ap.add_argument("--populations", type=int, default=1,
+    ap.add_argument("--populations", type=int, default=0,
                     help="split the resident games of a GPU into this many engines, each on its own HIP stream and host thread: "
-                         "one population's tree kernel and convolution tails overlap the other's CNN work")
+                         "one population's tree kernel and convolution tails overlap the other's CNN work (default: othello 2, "
+                         "other games 1)")
+    ap.add_argument("--no-alone-pass", action="store_true",
+                    help="with several populations: skip the extra one-population step that measures the kernels running alone")
     ap.add_argument("--resign-threshold", type=float, default=-1.0,
                     help="extension (BASELINE config 5), 0 = off as in the reference (default: off, go19: 0.05)")
     ap.add_argument("--resign-min-ply", type=int, default=-1, help="default 0 (go19: 60)")
@@ -218,109 +221,175 @@ def main():
     if args.model == "cnn":
         model_path = trace_to_file(make_network(G["engine"], args.blocks, args.channels, seed=0),
                                    os.path.join(tmpdir, f"traced_bench_r{rank}.pt"), G["engine"])
-    total_steps = args.steps + args.warmup
-    # unique RNG streams for every game of every step of every rank
-    pops = max(1, args.populations)
-    if args.concurrent % pops or games % pops:
-        raise SystemExit("--populations must divide --concurrent and --games")
-    engines = []
-    t_load = time.perf_counter()
-    for p in range(pops):
-        cfg = E.default_config(G["engine"], lib, device=local_rank, concurrent_games=args.concurrent // pops,
-                               num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
-                               stream_base=1 + (rank * pops + p) * (games // pops) * (total_steps + 2),
-                               profile=0 if args.no_profile else 1, own_stream=1 if pops > 1 else 0,
-                               resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
-        en = E.Engine(cfg, lib)
-        en.set_model(model_path if model_path else args.model)
-        engines.append(en)
-    eng = engines[0]
-    t_load = time.perf_counter() - t_load
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gather_s = [0.0]
-    shard_bytes = [0]
+    stream_cursor = [1 + rank * (1 << 24)]      # unique RNG streams for every game of every step of every rank and pass
 
-    def emit_records(en):
-        """The finished games' compact records, packed ON THE DEVICE from the engine's record buffers (records_kernel.h).
-        N > 1: the packed shards are gathered to rank 0 by the collective backend on the tensors where they lie (RCCL: device
-        memory, no host bounce - SURVEY section 8e).  N = 1: the shard is copied to the host once (what a worker would write out)."""
-        plies, _, nbytes = en.records_info()
-        shard = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        en.pack_records_into(shard.data_ptr(), nbytes)
-        en.finish()
-        shard_bytes[0] = nbytes
-        if dist is None:
-            host = shard.cpu()
-            return int(host[:16].view(torch.int64)[1])            # head[1] = plies of the shard
-        shards = gather_packed(shard if comm_device.type == "cuda" else shard.cpu(), nbytes, dist)
-        torch.cuda.synchronize()
-        return sum(sh["total_plies"] for sh in shards) if shards is not None else plies
+    def measure(pops, steps, warmup):
+        """One timed region: `pops` engines (each on its own HIP stream and host thread when pops > 1) play `steps` steps of
+        `games` games per GPU.  Returns the wall time, the counter deltas and the busy times of the two profiled kernels."""
+        if args.concurrent % pops or games % pops:
+            raise SystemExit("--populations must divide --concurrent and --games")
+        engines = []
+        t_load = time.perf_counter()
+        for p in range(pops):
+            cfg = E.default_config(G["engine"], lib, device=local_rank, concurrent_games=args.concurrent // pops,
+                                   num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
+                                   stream_base=stream_cursor[0],
+                                   profile=0 if args.no_profile else 1, own_stream=1 if pops > 1 else 0,
+                                   resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
+            stream_cursor[0] += (games // pops) * (steps + warmup + 2)
+            en = E.Engine(cfg, lib)
+            en.set_model(model_path if model_path else args.model)
+            engines.append(en)
+        t_load = time.perf_counter() - t_load
+        gather_s = [0.0]
+        shard_bytes = [0]
 
-    def play(en, n_games):
-        en.begin(n_games)
-        done = 0
-        while done < n_games:
-            done, _ = en.step(args.rounds_per_call)
+        def emit_records(en):
+            """The finished games' compact records, packed ON THE DEVICE from the engine's record buffers (records_kernel.h).
+            N > 1: the packed shards are gathered to rank 0 by the collective backend on the tensors where they lie (RCCL: device
+            memory, no host bounce - SURVEY section 8e).  N = 1: the shard is copied to the host once (what a worker would write out)."""
+            plies, _, nbytes = en.records_info()
+            shard = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            en.pack_records_into(shard.data_ptr(), nbytes)
+            en.finish()
+            shard_bytes[0] = nbytes
+            if dist is None:
+                host = shard.cpu()
+                return int(host[:16].view(torch.int64)[1])            # head[1] = plies of the shard
+            shards = gather_packed(shard if comm_device.type == "cuda" else shard.cpu(), nbytes, dist)
+            torch.cuda.synchronize()
+            return sum(sh["total_plies"] for sh in shards) if shards is not None else plies
 
-    def one_step():
-        if pops == 1:
-            play(engines[0], games)
-        else:                                       # one host thread per population (the C calls release the GIL)
-            import threading
-            ths = [threading.Thread(target=play, args=(engines[k], games // pops)) for k in range(pops)]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
+        def play(en, n_games):
+            en.begin(n_games)
+            done = 0
+            while done < n_games:
+                done, _ = en.step(args.rounds_per_call)
+
+        def one_step():
+            if pops == 1:
+                play(engines[0], games)
+            else:                                       # one host thread per population (the C calls release the GIL)
+                import threading
+                ths = [threading.Thread(target=play, args=(engines[k], games // pops)) for k in range(pops)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+            plies = 0
+            tg = time.perf_counter()
+            for en in engines:
+                plies += emit_records(en)
+            gather_s[0] += time.perf_counter() - tg
+            return plies
+
+        # untimed primer: first-touch of the arenas
+        for en in engines:
+            en.begin(games // pops)
+            en.step(4)
+        barrier()
+        for _ in range(warmup):
+            one_step()
+
+        def all_stats():
+            tot = {}
+            for en in engines:
+                for k, v in en.stats().items():
+                    if isinstance(v, (int, float)):
+                        tot[k] = max(tot.get(k, 0), v) if k in ("max_nodes_in_arena", "cyc_max_slot_launch") else tot.get(k, 0) + v
+            return tot
+
+        st0 = all_stats()
+        lib.sprl_profile_busy_reset()
+        gather_s[0] = 0.0
+        barrier()
+        t0 = time.perf_counter()
         plies = 0
-        tg = time.perf_counter()
+        for _ in range(steps):
+            plies += one_step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        st1 = all_stats()
+        # several populations: launches of one kernel overlap on different streams; busy = time with >= 1 launch executing
+        tree_busy, tree_sum = E.profile_busy(lib, 0)
+        conv_busy, conv_sum = E.profile_busy(lib, 1) if model_path else (None, None)
+        d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
+        info = engines[0].evaluator_info() if model_path else args.model
         for en in engines:
-            plies += emit_records(en)
-        gather_s[0] += time.perf_counter() - tg
-        return plies
+            en.close()
+        return dict(pops=pops, steps=steps, elapsed=elapsed, d=d, st1=st1, tree_busy=tree_busy, tree_sum=tree_sum,
+                    conv_busy=conv_busy, conv_sum=conv_sum, t_load=t_load, gather_s=gather_s[0], shard_bytes=shard_bytes[0],
+                    evaluator=info)
 
-    # untimed primer: first-touch of the arenas
-    for en in engines:
-        en.begin(games // pops)
-        en.step(4)
-    barrier()
+    def rooflines(M):
+        """(roofline of the trunk convolution or None, roofline of the tree kernel or None) of one measure() result.
+        achieved = algorithmic bytes / flops of all launches / time the kernel was executing.  One engine: that time is the sum
+        of the launch durations (= launches x avg_launch_ms).  Several engines (--populations): their launches overlap on
+        different HIP streams, the time is the union of the launch intervals (sprl_profile_busy), from the same HIP events."""
+        d, mp = M["d"], M["pops"]
+        if args.no_profile or d["kernel_ms"] <= 0:
+            return None, None
+        bpt, _ = algorithmic_bytes_per_traversal(d, A=G["A"], mask_bytes=G["mask_bytes"], board_bytes=G["board_bytes"],
+                                                 s_in=G["planes"] * G["rows"] * G["cols"] * 4)
+        tree_time_ms = M["tree_busy"] if (mp > 1 and M["tree_busy"]) else d["kernel_ms"]
+        achieved = d["traversals"] * bpt / (tree_time_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "tree_kernel_traffic.json")
+        if os.path.exists(tpath) and args.game == "othello":   # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
+            with open(tpath) as tf:
+                traffic = json.load(tf).get("hbm_bytes_per_launch")
+        tree = {"bound": "hbm", "kernel": f"step_kernel ({G['label']}: select/expand/backup/re-root)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bytes_per_traversal": bpt,
+                "avg_launch_ms": d["kernel_ms"] / max(1, d["kernel_launches"]),
+                "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"]),
+                "launch_ms_sum": d["kernel_ms"], "busy_ms": M["tree_busy"],
+                "overlap": (M["tree_sum"] / M["tree_busy"]) if M["tree_busy"] else None, "populations": mp}
+        if d.get("conv_ms", 0) <= 0:
+            return None, tree
+        # the dominant kernel by time: the trunk convolution of the CNN (cnn_wino.hip), fp32 MFMA-bound.
+        # Algorithmic work per board and launch = the Winograd-domain products the kernel must issue:
+        # 4 tiles x 36 positions x 64 x 64 multiply-adds (4x fewer than the direct 3x3 convolution).
+        tiles = ((G["rows"] + 3) // 4) * ((G["cols"] + 3) // 4)
+        flop_per_board = 2 * tiles * 36 * 64 * 64
+        flop = d["conv_boards"] * flop_per_board
+        conv_time_ms = M["conv_busy"] if (mp > 1 and M["conv_busy"]) else d["conv_ms"]
+        tf = flop / (conv_time_ms * 1e-3) / 1e12
+        ctraffic = None
+        cpath = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
+        if os.path.exists(cpath) and mp == 1:                   # measured per launch of one population's full-size batch
+            with open(cpath) as tf_:
+                ctraffic = json.load(tf_).get("hbm_bytes_per_launch")
+        conv = {"bound": "mfma", "kernel": "wino_conv64 (3x3 conv 64->64 + BN/residual/ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
+                "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                "traffic": ctraffic, "share_of_step_time": conv_time_ms * 1e-3 / M["elapsed"],
+                "launch_ms_sum": d["conv_ms"], "busy_ms": M["conv_busy"],
+                "overlap": (M["conv_sum"] / M["conv_busy"]) if M["conv_busy"] else None,
+                "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
+                "boards_per_launch": d["conv_boards"] / max(1, d["conv_launches"]),
+                "flop_per_board": flop_per_board,
+                "direct_conv_equivalent_tflops": tf * 4.0, "populations": mp}
+        return conv, tree
 
-    for _ in range(args.warmup):
-        one_step()
-
-    def all_stats():
-        tot = {}
-        for en in engines:
-            for k, v in en.stats().items():
-                if isinstance(v, (int, float)):
-                    tot[k] = max(tot.get(k, 0), v) if k in ("max_nodes_in_arena", "cyc_max_slot_launch") else tot.get(k, 0) + v
-        return tot
-
-    st0 = all_stats()
-    lib.sprl_profile_busy_reset()
-    gather_s[0] = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    plies = 0
-    for _ in range(args.steps):
-        plies += one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    st1 = all_stats()
-    # several populations: launches of one kernel overlap on different streams; busy = time with >= 1 launch executing
-    tree_busy, tree_sum = E.profile_busy(lib, 0)
-    conv_busy, conv_sum = E.profile_busy(lib, 1) if model_path else (None, None)
-    d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
+    pops = args.populations if args.populations > 0 else (G.get("populations", 1) if args.model == "cnn" else 1)
+    M = measure(pops, args.steps, args.warmup)
+    elapsed, d, st1 = M["elapsed"], M["d"], M["st1"]
+    t_load, gather_s, shard_bytes = M["t_load"], [M["gather_s"]], [M["shard_bytes"]]
+    # the same kernels with nothing running beside them: a separate untimed-for-`value` pass with ONE population (one step)
+    M1 = None
+    if pops > 1 and not args.no_profile and not args.no_alone_pass:
+        M1 = measure(1, 1, 0)
 
     if rank == 0:
         total_games = games * args.steps * world
@@ -344,7 +413,7 @@ def main():
                                    f"{games} games/GPU/step, batch {G['bq'].split('/')[0]}/queue {G['bq'].split('/')[1]}, {G['sym']}, {G['noise']}" +
                                    (f", resign threshold {args.resign_threshold}" if args.resign_threshold > 0 else "") +
                                    (f", {pops} populations on {pops} HIP streams" if pops > 1 else ""),
-                       "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32, " + eng.evaluator_info() if model_path else args.model),
+                       "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32, " + M["evaluator"] if model_path else args.model),
                        "parallelism": (f"game-sharded x{world}, records packed on the device, one gather per step over {backend_name}"
                                        if world > 1 else "1 GPU")},
             "expansions_per_sec": d["expansions"] * world / elapsed,
@@ -365,51 +434,17 @@ def main():
             out["phase_cycles_share"]["noise_cycles_per_move"] = d["cyc_noise"] / max(1, d["plies"])
             out["phase_cycles_share"]["per_level_cycles"] = {k: d["cyc_lvl_" + k] / max(1, d["levels"]) for k in ("wait", "pick", "desc")}
             out["phase_cycles_share"]["total_cycles_per_slot_launch"] = d["cyc_total"] / max(1, d["kernel_launches"]) / args.concurrent
-        if not args.no_profile and d["kernel_ms"] > 0:
-            # achieved = algorithmic bytes of all launches / time the kernel was executing.  One engine: that time is the sum
-            # of the launch durations (= launches x avg_launch_ms).  Several engines (--populations): their launches overlap on
-            # different HIP streams, the time is the union of the launch intervals (sprl_profile_busy), from the same events.
-            tree_time_ms = tree_busy if (pops > 1 and tree_busy) else d["kernel_ms"]
-            achieved = d["traversals"] * bpt / (tree_time_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "tree_kernel_traffic.json")
-            if os.path.exists(tpath) and args.game == "othello":   # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
-                with open(tpath) as tf:
-                    traffic = json.load(tf).get("hbm_bytes_per_launch")
-            tree = {"bound": "hbm", "kernel": f"step_kernel ({G['label']}: select/expand/backup/re-root)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "bytes_per_traversal": bpt,
-                    "avg_launch_ms": d["kernel_ms"] / max(1, d["kernel_launches"]),
-                    "traversals_per_launch": d["traversals"] / max(1, d["kernel_launches"]),
-                    "launch_ms_sum": d["kernel_ms"], "busy_ms": tree_busy,
-                    "overlap": (tree_sum / tree_busy) if tree_busy else None}
-            if d.get("conv_ms", 0) > 0:
-                # the dominant kernel by time: the trunk convolution of the CNN (cnn_wino.hip), fp32 MFMA-bound.
-                # Algorithmic work per board and launch = the Winograd-domain products the kernel must issue:
-                # 4 tiles x 36 positions x 64 x 64 multiply-adds (4x fewer than the direct 3x3 convolution).
-                tiles = ((G["rows"] + 3) // 4) * ((G["cols"] + 3) // 4)
-                flop_per_board = 2 * tiles * 36 * 64 * 64
-                flop = d["conv_boards"] * flop_per_board
-                conv_time_ms = conv_busy if (pops > 1 and conv_busy) else d["conv_ms"]
-                tf = flop / (conv_time_ms * 1e-3) / 1e12
-                ctraffic = None
-                cpath = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
-                if os.path.exists(cpath):
-                    with open(cpath) as tf_:
-                        ctraffic = json.load(tf_).get("hbm_bytes_per_launch")
-                out["roofline"] = {"bound": "mfma", "kernel": "wino_conv64 (3x3 conv 64->64 + BN/residual/ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
-                                   "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                                   "traffic": ctraffic, "share_of_step_time": conv_time_ms * 1e-3 / elapsed,
-                                   "launch_ms_sum": d["conv_ms"], "busy_ms": conv_busy,
-                                   "overlap": (conv_sum / conv_busy) if conv_busy else None,
-                                   "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
-                                   "boards_per_launch": d["conv_boards"] / max(1, d["conv_launches"]),
-                                   "flop_per_board": flop_per_board,
-                                   "direct_conv_equivalent_tflops": tf * 4.0}
-                out["roofline_tree"] = tree
-            else:
-                out["roofline"] = tree
+        conv_rl, tree_rl = rooflines(M)
+        if conv_rl is not None:
+            out["roofline"], out["roofline_tree"] = conv_rl, tree_rl
+        elif tree_rl is not None:
+            out["roofline"] = tree_rl
+        if M1 is not None:
+            c1, t1 = rooflines(M1)
+            out["one_population_pass"] = {
+                "what": "the same workload with ONE population (no kernel of another stream beside it), one step, after the timed "
+                        "region: per-launch figures comparable to the rocprofv3 averages under profiles/",
+                "games_per_sec": games * world / M1["elapsed"], "roofline": c1, "roofline_tree": t1}
         if world == 1 and not args.no_cpu_baseline and args.game == "othello":
             mp_model = model_path
             if mp_model is None:
@@ -426,8 +461,6 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": 0, "kind": "reference",
                                        "sample": f"failed: {exc}"}
         print(json.dumps(out), flush=True)
-    for en in engines:
-        en.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
