@@ -332,6 +332,7 @@ constexpr int PS_G = 37, SS_G = 16 * PS_G;            // patch stride, channel-s
 constexpr int IN_BUF_G = 8 * SS_G;
 constexpr int LDS_FLOATS_G = 2 * IN_BUF_G + 4 * V_G2;  // 74.8 KB: two workgroups per CU
 constexpr int NLD_G = (8 * 16 * 36) / NTHR2;          // 18 patch values per thread and chunk
+constexpr unsigned SLACK_G = 32;                      // bytes that must be readable behind x and res (see the kernel)
 
 __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -371,12 +372,17 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
     const unsigned act_bytes = (unsigned)batch * 64u * (unsigned)HW * 4u;
     // the input descriptor starts 16 bytes before x: a patch's first column is col0 - 1, so with the bias no offset is ever
     // negative (a negative per-lane offset plus a positive instruction offset must not depend on how the range check wraps)
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x - 16), 0, act_bytes + 16u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes : 0u, 0x00020000);
+    // A patch row (6 floats) is one 16-byte + one 8-byte load and a residual row one 16-byte load, at 4-byte alignment; at a
+    // board's edge they run into the next row / plane (those values are replaced by zeros below / never stored) and at the very
+    // end of the tensor up to 20 bytes past it, at its very start 4 bytes before it (the left neighbour of column 0): x must be
+    // readable from 16 bytes before its start, x and res for 32 bytes beyond their end (SLACK_G).
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x - 16), 0, act_bytes + 16u + SLACK_G, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes + SLACK_G : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, act_bytes, 0x00020000);
-    int ld_colsel[6], ld_rowoff[3];
+    int ld_rowoff[3];
+    bool ld_colok[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) ld_colsel[j] = (ld_col + j >= 0 && ld_col + j < W) ? 0 : OOB;
+    for (int j = 0; j < 6; ++j) ld_colok[j] = ld_col + j >= 0 && ld_col + j < W;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int row = ld_row + i;
@@ -389,14 +395,16 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
         const int k = 16 * (g >> 2) + 4 * (ld_slot & 3) + (g & 3);
         const int koff = k * HW * 4;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                pre[i * 6 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ((ld_rowoff[i] + koff) | ld_colsel[j]) + j * 4, 0, 0));
+        for (int i = 0; i < 3; ++i) {
+            const f4 a4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_rowoff[i] + koff, 0, 0));
+            const f2 a2 = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rx, ld_rowoff[i] + koff + 16, 0, 0));
+            pre[i * 6 + 0] = a4[0]; pre[i * 6 + 1] = a4[1]; pre[i * 6 + 2] = a4[2]; pre[i * 6 + 3] = a4[3];
+            pre[i * 6 + 4] = a2[0]; pre[i * 6 + 5] = a2[1];
+        }
     };
     auto lstore = [&](float* buf) {
 #pragma unroll
-        for (int q = 0; q < NLD_G; ++q) buf[ld_lds + q] = pre[q];
+        for (int q = 0; q < NLD_G; ++q) buf[ld_lds + q] = ld_colok[q % 6] ? pre[q] : 0.0f;      // columns off the board
     };
     const int patch0 = (gl * 4 + c_sub) * SS_G + tl * PS_G + wa * 6;
     const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
@@ -485,14 +493,11 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
 #pragma unroll
     for (int j = 0; j < 4; ++j) o_colsel[j] = (t_col0 + j < W) ? 0 : OOB;
     // residual values of output component r (channel 16 kb + 4 c_sub + r), requested one component ahead of their use
-    float rres[2][16];
-    auto rload = [&](int r, float (&dst)[16]) {
+    f4 rres[2][4];
+    auto rload = [&](int r, f4 (&dst)[4]) {
         const int koff = (16 * kb + 4 * c_sub + r) * HW * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                dst[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ((o_rowoff[i] + koff) | o_colsel[j]) + j * 4, 0, 0));
+        for (int i = 0; i < 4; ++i) dst[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, o_rowoff[i] + koff, 0, 0));
     };
     rload(0, rres[0]);
 #pragma unroll
@@ -511,7 +516,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = o[i][j] * sc + sh + rres[r & 1][i * 4 + j];
+                float v = o[i][j] * sc + sh + rres[r & 1][i][j];
                 if (relu) v = v > 0.0f ? v : 0.0f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ((o_rowoff[i] + koff) | o_colsel[j]) + j * 4, 0, 0);
             }
@@ -562,6 +567,9 @@ extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const floa
 }
 
 // Any board size, NCHW activations [batch][64][H][W] in and out (res may be null; y must not alias x); same weights `u`.
+// x must be readable from 16 bytes before its start, x and res for sprl_wino_nchw_slack() bytes behind their end (patch rows
+// are fetched 16 + 8 bytes at a time, starting one column left of the tile).
+extern "C" int sprl_wino_nchw_slack(void) { return (int)SLACK_G; }
 extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                      float* y, int batch, int H, int W, int relu, void* stream) {
     if (batch <= 0) return 0;

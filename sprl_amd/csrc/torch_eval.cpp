@@ -274,6 +274,13 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                                    p.data_ptr<float>(), v.data_ptr<float>(), B, 64, HW, n.pc, n.vc, W, nullptr) == 0;
 }
 
+// NCHW activation [B][64][H][W] with 16 readable bytes in front of it and 32 behind it (sprl_wino_conv64_nchw fetches patch
+// rows 16 + 8 bytes at a time, starting one column left of the tile)
+at::Tensor nchw_act(int64_t B, int H, int W, const at::TensorOptions& opts) {
+    const int64_t n = B * 64 * H * W;
+    return at::empty({ n + 12 }, opts).narrow(0, 4, n).view({ B, 64, H, W });
+}
+
 bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
                     float* logits_out, float* value_out, bool* wrote_outputs) {
     const NativeNet& n = mdl->native;
@@ -287,7 +294,7 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
         at::Tensor x;
         if ((P0 == 3 || P0 == 17) && n.stem_w.size(0) == 64 && in.is_contiguous() && !getenv("SPRL_TORCH_NO_NCHW_STEM")) {
             // hand-written stem for any board size (Go 9x9 / 19x19): conv + folded BN + ReLU in one kernel
-            x = at::empty({ in.size(0), 64, H0, W0 }, in.options());
+            x = nchw_act(in.size(0), H0, W0, in.options());
             if (sprl_stem_conv3x3_nchw(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
                                        n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), in.size(0), P0, H0, W0, nullptr) != 0)
                 return false;
@@ -300,8 +307,13 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
         const bool trunk_wino = n.wino && H0 <= 64 && W0 <= 64 && !getenv("SPRL_TORCH_NO_WINOGRAD_NCHW");
         at::Tensor ya, za;
         if (trunk_wino) {
-            ya = at::empty_like(x);
-            za = at::empty_like(x);
+            if (x.storage_offset() < 4 || x.storage().nbytes() < (size_t)(x.storage_offset() + x.numel()) * 4 + 32) {   // (library stem: no slack yet)
+                at::Tensor xs = nchw_act(x.size(0), H0, W0, x.options());
+                xs.copy_(x);
+                x = xs;
+            }
+            ya = nchw_act(x.size(0), H0, W0, x.options());
+            za = nchw_act(x.size(0), H0, W0, x.options());
         }
         for (const auto& b : n.blocks) {
             if (trunk_wino) {

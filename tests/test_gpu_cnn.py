@@ -100,11 +100,20 @@ def test_wino_conv_general_boards_nchw(plug, H, W, B):
     """The any-board variant (workgroup = 16 tiles, patches gathered from NCHW) against conv2d in float64."""
     import torch
     torch.manual_seed(H * 1000 + W * 10 + B)
-    x = torch.randn(B, 64, H, W, device="cuda")
+
+    def act():
+        """[B][64][H][W] with the readable bytes around it that the kernel asks for (patch rows are fetched 16 + 8 bytes at a
+        time); the slack holds NaN: nothing read from it may reach a result."""
+        n = B * 64 * H * W
+        flat = torch.full((n + 12,), float("nan"), device="cuda")      # 16 bytes in front as well (left neighbour of column 0)
+        flat[4:n + 4] = torch.randn(n, device="cuda")
+        return flat[4:n + 4].view(B, 64, H, W)
+
+    x = act()
     w = torch.randn(64, 64, 3, 3, device="cuda") * 0.06
     scale = torch.rand(64, device="cuda") + 0.5
     shift = torch.randn(64, device="cuda") * 0.3
-    res = torch.randn(B, 64, H, W, device="cuda")
+    res = act()
     u = np.zeros(36 * 64 * 64, np.float32)
     wc = np.ascontiguousarray(w.cpu().numpy())          # keep the host copy alive across the call
     plug.sprl_wino_transform_weights(wc.ctypes.data, u.ctypes.data)
