@@ -79,6 +79,7 @@ struct TorchPlugin {
     void* (*load)(const char*, int, char*, int) = nullptr;
     void* (*load_buffer)(const void*, long long, int, char*, int) = nullptr;
     int (*forward)(void*, const float*, int, int, int, int, float*, int, float*, char*, int) = nullptr;
+    int (*forward_on)(void*, const float*, int, int, int, int, float*, int, float*, void*, char*, int) = nullptr;
     void (*release)(void*) = nullptr;
     int (*is_native)(void*) = nullptr;
     int (*forward_dev)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int) = nullptr;
@@ -171,6 +172,7 @@ int load_torch_plugin(sprl_engine* e) {
     e->torch.load = (void* (*)(const char*, int, char*, int))dlsym(lib, "sprl_torch_load");
     e->torch.load_buffer = (void* (*)(const void*, long long, int, char*, int))dlsym(lib, "sprl_torch_load_buffer");
     e->torch.forward = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, char*, int))dlsym(lib, "sprl_torch_forward");
+    e->torch.forward_on = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, void*, char*, int))dlsym(lib, "sprl_torch_forward_on");
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
     e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
     e->torch.forward_dev = (int (*)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int))dlsym(
@@ -461,11 +463,11 @@ static int set_model_common(sprl_engine* e, const char* model, const void* bytes
                                             e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, e->stream, perr, (int)sizeof(perr)) == 0;
         be::sync();
     }
-    if (e->stream && !e->dev_batch) {
+    if (e->stream && !e->dev_batch && !e->torch.forward_on) {
         e->torch.release(m);
         e->torch_model = nullptr;
-        return fail(SPRL_E_CONFIG, "own_stream needs an evaluator that runs on the engine's stream: the hand-written CNN path "
-                                   "(reference architecture, 64-channel trunk) or an in-kernel evaluator");
+        return fail(SPRL_E_CONFIG, "own_stream needs an evaluator that runs on the engine's stream: this network plugin has no "
+                                   "sprl_torch_forward_on");
     }
     if (e->cfg.profile && e->torch.profile_enable) e->torch.profile_enable(m, 1);
     e->forward_cb = nullptr;
@@ -620,8 +622,12 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
                     rc = e->forward_cb(e->forward_user, P.nn_dense, batch, e->nn_logits, e->nn_value);
                     if (rc) snprintf(err, sizeof(err), "forward callback returned %d", rc);
                 } else {
-                    rc = e->torch.forward(e->torch_model, P.nn_dense, batch, e->g.planes, e->g.rows, e->g.cols, e->nn_logits,
-                                          e->g.A, e->nn_value, err, (int)sizeof(err));
+                    // on the engine's own stream when it has one (boards wider than 8, other architectures: batch size on the host)
+                    rc = (e->stream && e->torch.forward_on)
+                             ? e->torch.forward_on(e->torch_model, P.nn_dense, batch, e->g.planes, e->g.rows, e->g.cols, e->nn_logits,
+                                                   e->g.A, e->nn_value, e->stream, err, (int)sizeof(err))
+                             : e->torch.forward(e->torch_model, P.nn_dense, batch, e->g.planes, e->g.rows, e->g.cols, e->nn_logits,
+                                                e->g.A, e->nn_value, err, (int)sizeof(err));
                 }
                 if (rc) {
                     e->running = false;

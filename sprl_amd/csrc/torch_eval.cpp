@@ -9,6 +9,8 @@
 #include <torch/csrc/jit/ir/ir.h>
 #include <torch/csrc/jit/passes/freeze_module.h>
 #include <hip/hip_runtime_api.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/script.h>
 #include <torch/torch.h>
 
@@ -282,13 +284,13 @@ at::Tensor nchw_act(int64_t B, int H, int W, const at::TensorOptions& opts) {
 }
 
 bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
-                    float* logits_out, float* value_out, bool* wrote_outputs) {
+                    float* logits_out, float* value_out, bool* wrote_outputs, void* stream = nullptr) {
     const NativeNet& n = mdl->native;
     at::Tensor p, v;
     const int H0 = (int)in.size(2), W0 = (int)in.size(3), P0 = (int)in.size(1);
     const bool wino = n.wino && (P0 == 3 || P0 == 17) && ((H0 == 8 && W0 == 8) || (H0 == 6 && W0 == 7) || (H0 == 7 && W0 == 7));
     if (wino) {
-        if (!forward_wino(mdl, in, p, v, prof, logits_out, value_out, wrote_outputs)) return false;
+        if (!forward_wino(mdl, in, p, v, prof, logits_out, value_out, wrote_outputs, nullptr, stream)) return false;
         if (*wrote_outputs) return true;
     } else {
         at::Tensor x;
@@ -296,7 +298,7 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
             // hand-written stem for any board size (Go 9x9 / 19x19): conv + folded BN + ReLU in one kernel
             x = nchw_act(in.size(0), H0, W0, in.options());
             if (sprl_stem_conv3x3_nchw(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
-                                       n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), in.size(0), P0, H0, W0, nullptr) != 0)
+                                       n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), in.size(0), P0, H0, W0, stream) != 0)
                 return false;
         } else {
             x = at::conv2d(in, n.stem_w, {}, 1, 1);
@@ -319,9 +321,9 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
             if (trunk_wino) {
                 const int B0 = (int)x.size(0);
                 if (sprl_wino_conv64_nchw(x.data_ptr<float>(), b.u1.data_ptr<float>(), b.s1.data_ptr<float>(), b.t1.data_ptr<float>(),
-                                          nullptr, ya.data_ptr<float>(), B0, H0, W0, 1, nullptr) != 0 ||
+                                          nullptr, ya.data_ptr<float>(), B0, H0, W0, 1, stream) != 0 ||
                     sprl_wino_conv64_nchw(ya.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(), b.t2.data_ptr<float>(),
-                                          x.data_ptr<float>(), za.data_ptr<float>(), B0, H0, W0, 1, nullptr) != 0)
+                                          x.data_ptr<float>(), za.data_ptr<float>(), B0, H0, W0, 1, stream) != 0)
                     return false;
                 std::swap(x, za);
                 continue;
@@ -337,7 +339,7 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
         p = at::empty({ B, (int64_t)n.pc * HW }, x.options());
         v = at::empty({ B, (int64_t)n.vc * HW }, x.options());
         if (sprl_heads_conv1x1_relu(x.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
-                                    p.data_ptr<float>(), v.data_ptr<float>(), B, C, HW, n.pc, n.vc, 0, nullptr) != 0)
+                                    p.data_ptr<float>(), v.data_ptr<float>(), B, C, HW, n.pc, n.vc, 0, stream) != 0)
             return false;
     }
     logits = at::addmm(n.pfc_b, p, n.pfc_w);
@@ -436,11 +438,30 @@ static void* load_common(const char* path, const void* bytes, long long nbytes, 
     }
 }
 
+static int forward_common(void* handle, const float* planes, int batch, int nplanes, int rows, int cols, float* logits,
+                          int actions, float* value, void* stream, char* err, int errlen);
+
 int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes, int rows, int cols,
                        float* logits, int actions, float* value, char* err, int errlen) {
+    return forward_common(handle, planes, batch, nplanes, rows, cols, logits, actions, value, nullptr, err, errlen);
+}
+
+// The same forward with every kernel (ours and the library's) on the caller's HIP stream: an engine on a private stream
+// (sprl_config.own_stream) whose evaluator needs the batch size on the host - boards wider than 8, other architectures.
+int sprl_torch_forward_on(void* handle, const float* planes, int batch, int nplanes, int rows, int cols,
+                          float* logits, int actions, float* value, void* stream, char* err, int errlen) {
+    return forward_common(handle, planes, batch, nplanes, rows, cols, logits, actions, value, stream, err, errlen);
+}
+
+static int forward_common(void* handle, const float* planes, int batch, int nplanes, int rows, int cols, float* logits,
+                          int actions, float* value, void* stream, char* err, int errlen) {
     try {
         auto* m = static_cast<Model*>(handle);
         c10::InferenceMode guard;
+        std::unique_ptr<c10::hip::HIPStreamGuardMasqueradingAsCUDA> on_stream;       // LibTorch's own kernels follow
+        if (stream && m->device >= 0)
+            on_stream.reset(new c10::hip::HIPStreamGuardMasqueradingAsCUDA(
+                c10::hip::getStreamFromExternalMasqueradingAsCUDA((hipStream_t)stream, (c10::DeviceIndex)m->device)));
         auto opts = m->device >= 0
                         ? torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, (c10::DeviceIndex)m->device)
                         : torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCPU);
@@ -449,7 +470,7 @@ int sprl_torch_forward(void* handle, const float* planes, int batch, int nplanes
         bool wrote = false;
         const bool fuse_tail = m->device >= 0 && m->native.ok && m->native.pfc_w.size(1) == actions && !getenv("SPRL_TORCH_NO_FUSED_TAIL");
         if (m->native.ok && forward_native(m, in, lo, va, &m->prof, fuse_tail ? logits : nullptr,
-                                           fuse_tail ? value : nullptr, &wrote) && wrote)
+                                           fuse_tail ? value : nullptr, &wrote, stream) && wrote)
             return 0;
         if (!lo.defined()) {
             auto out = m->module.forward({ in }).toTuple();         // GridNetwork.hpp:99-102 (generic TorchScript path)

@@ -432,6 +432,38 @@ def test_private_stream_cnn_games_equal_null_stream_games(lib, traced_model):
     assert (d0.view(np.uint32) == d1.view(np.uint32)).all()
 
 
+def test_private_stream_go9_host_batch_path(lib, tmp_path):
+    """Boards wider than 8 need the batch size on the host (sprl_torch_forward_on): the whole forward - our kernels and the
+    library GEMMs of the FC tail - then runs on the engine's private stream.  Same configuration, same rounds, same batches:
+    the games of a private-stream engine equal those of a null-stream engine, also when two of them run from two threads."""
+    import threading
+    from sprl_amd.network import make_network, trace_to_file
+    model = trace_to_file(make_network("go9", 2, 64, seed=6), str(tmp_path / "traced_go9s.pt"), "go9")
+
+    def play(own, out, key, seed):
+        cfg = E.default_config("go9", lib, concurrent_games=8, num_traversals=32, seed=seed, own_stream=own)
+        eng = E.Engine(cfg, lib)
+        eng.set_model(model)
+        rec = eng.run(8)
+        out[key] = (rec.expand_boards(), rec.expand())
+        eng.close()
+
+    res = {}
+    play(0, res, "null5", 5)
+    play(0, res, "null6", 6)
+    play(1, res, "own5", 5)
+    ths = [threading.Thread(target=play, args=(1, res, f"thr{sd}", sd)) for sd in (5, 6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for a_key, b_key in (("null5", "own5"), ("null5", "thr5"), ("null6", "thr6")):
+        (b0, p0), (s0, d0, o0) = res[a_key]
+        (b1, p1), (s1, d1, o1) = res[b_key]
+        assert b0.shape == b1.shape and (b0 == b1).all() and (p0 == p1).all() and (o0 == o1).all(), (a_key, b_key)
+        assert (d0.view(np.uint32) == d1.view(np.uint32)).all(), (a_key, b_key)
+
+
 def test_go9_plugin_forward_matches_torchscript(lib, tmp_path):
     """9x9 boards: library convolutions + the hand-written bias/BN/ReLU(/residual) epilogue and fused 1x1 heads (H*W = 81 is
     not a multiple of 4: scalar epilogue form) and the hand-written NCHW stem (17 planes) against the plain TorchScript fp32
