@@ -136,12 +136,12 @@ GAMES = {
     "go7": dict(engine="go7", rows=7, cols=7, A=50, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8",
                 label="Go 7x7", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=8, board_bytes=49),
     "go9": dict(engine="go9", rows=9, cols=9, A=82, planes=17, concurrent=1024, traversals=1600, blocks=6, bq="16/8",
-                label="Go 9x9", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=11, board_bytes=81),
+                label="Go 9x9", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=11, board_bytes=81, populations=2),
     # config 5 names a resign threshold: on by default for this game (with random-init weights the decision is noise and games
     # end after ~min-ply moves; without it every game runs to the 722-ply cap, ~20 min per step)
     "go19": dict(engine="go19", rows=19, cols=19, A=362, planes=17, concurrent=256, traversals=1600, blocks=6, bq="16/8",
                  label="Go 19x19", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=46, board_bytes=361,
-                 resign_threshold=0.05, resign_min_ply=60),
+                 resign_threshold=0.05, resign_min_ply=60, populations=2),
 }
 
 
@@ -162,8 +162,8 @@ def main():
     ap.add_argument("--rounds-per-call", type=int, default=64)
     ap.add_argument("--populations", type=int, default=0,
                     help="split the resident games of a GPU into this many engines, each on its own HIP stream and host thread: "
-                         "one population's tree kernel and convolution tails overlap the other's CNN work (default: othello 2, "
-                         "other games 1)")
+                         "one population's tree kernel and convolution tails overlap the other's CNN work (default: othello, "
+                         "go9, go19: 2, other games 1)")
     ap.add_argument("--no-alone-pass", action="store_true",
                     help="with several populations: skip the extra one-population step that measures the kernels running alone")
     ap.add_argument("--resign-threshold", type=float, default=-1.0,
@@ -388,7 +388,7 @@ def main():
     t_load, gather_s, shard_bytes = M["t_load"], [M["gather_s"]], [M["shard_bytes"]]
     # the same kernels with nothing running beside them: a separate untimed-for-`value` pass with ONE population (one step)
     M1 = None
-    if pops > 1 and not args.no_profile and not args.no_alone_pass:
+    if pops > 1 and not args.no_profile and not args.no_alone_pass and args.game == "othello":     # (a Go step is minutes long)
         M1 = measure(1, 1, 0)
 
     if rank == 0:
