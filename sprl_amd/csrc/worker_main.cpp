@@ -87,7 +87,7 @@ int main(int argc, char** argv) {
     if (*end) return usage();
     const long num_tasks = strtol(argv[3], &end, 10);
     if (*end) return usage();
-    int cover = 1, device = 0, concurrent = 0, format = 1, num_iters = -1;
+    int cover = 1, device = 0, concurrent = 0, format = 1, num_iters = -1, populations = 1;
     long long seed = 0;
     double poll = 30.0;                                           // MODEL_PATH_WAIT_INTERVAL, GridWorker.hpp:23
     float resign = 0.0f;
@@ -121,6 +121,7 @@ int main(int argc, char** argv) {
                                                           // rendez-vous still happens, the file's content is not loaded
         else if (a == "--resign-threshold") { if (!(v = val())) return usage(); resign = (float)atof(v); }
         else if (a == "--resign-min-ply") { if (!(v = val())) return usage(); resign_min_ply = atoi(v); }
+        else if (a == "--populations") { if (!(v = val())) return usage(); populations = atoi(v); }
         else return usage();
     }
     if (num_tasks != k.num_worker_tasks) {                        // the reference asserts (OTHWorker.cpp:42)
@@ -128,6 +129,7 @@ int main(int argc, char** argv) {
         return 1;
     }
     if (cover < 1 || task_id < 0 || task_id + cover > num_tasks || k.num_groups < 1 || k.num_worker_tasks % k.num_groups) return usage();
+    if (populations < 1 || populations > cover || populations > 8) return usage();
     if (num_iters < 0) num_iters = k.num_iters;
     if (seed == 0)                                                // the reference seeds from random_device
         seed = (long long)(std::chrono::steady_clock::now().time_since_epoch().count() & 0x7fffffffffffLL) | 1;
@@ -151,16 +153,21 @@ int main(int argc, char** argv) {
         dirs.push_back(d);
     }
 
+    // The worker loop for the covered tasks [first, first + count): one engine, kept across iterations.  --populations P splits
+    // the covered tasks into P such ranges, each with its own engine on a private HIP stream and its own host thread: the tree
+    // kernel of one population overlaps the network forward of the other (+7 % games/s on Othello).
+    auto run_range = [&](const int first, const int count, const int pop) -> int {
     sprl_engine* eng = nullptr;
     int eng_sig[4] = { -1, -1, -1, -1 };                            // traversals, batch, queue, concurrent of the live engine
-    int next_stream = 1;
+    int next_stream = 1 + pop * (1 << 27);                          // disjoint RNG stream ranges per population
     auto fail = [&](const char* what) {
         fprintf(stderr, "%s: %s\n", what, sprl_last_error());
         if (eng) sprl_engine_destroy(eng);
         return 2;
     };
+    const int cover = count;                                        // (shadows the whole range inside this population)
     for (int it = 0; it < num_iters; ++it) {
-        printf("Starting iteration %d...\n", it);                                                  // GridWorker.hpp:112
+        if (pop == 0) printf("Starting iteration %d...\n", it);                                    // GridWorker.hpp:112
         fflush(stdout);
         std::string model = model0;
         if (it > 0) {
@@ -171,7 +178,8 @@ int main(int argc, char** argv) {
         const int games = it == 0 ? k.init_games : k.games, trav = it == 0 ? k.init_traversals : k.traversals;
         const int mb = it == 0 ? k.init_max_batch : k.max_batch, mq = it == 0 ? k.init_max_queue : k.max_queue;
         const int total = games * cover;
-        const int conc = concurrent > 0 && concurrent < total ? concurrent : total;
+        const int conc_cap = concurrent > 0 ? (concurrent + populations - 1) / populations : 0;
+        const int conc = conc_cap > 0 && conc_cap < total ? conc_cap : total;
         if (!eng || eng_sig[0] != trav || eng_sig[1] != mb || eng_sig[2] != mq || eng_sig[3] != conc) {
             if (eng) sprl_engine_destroy(eng);
             eng = nullptr;
@@ -186,6 +194,7 @@ int main(int argc, char** argv) {
             cfg.dir_alpha = k.dir_alpha;
             cfg.seed = (uint64_t)seed;
             cfg.stream_base = next_stream;
+            cfg.own_stream = populations > 1 ? 1 : 0;
             cfg.resign_threshold = resign;
             cfg.resign_min_ply = resign_min_ply;
             if (sprl_engine_create(&cfg, &eng) != 0) return fail("engine");
@@ -199,7 +208,7 @@ int main(int argc, char** argv) {
         for (int t = 0; t < cover; ++t) {
             sprl_records part;
             if (sprl_records_slice(&rec, t * games, games, &part) != 0) return fail("slice");
-            const std::string prefix = dirs[(size_t)t] + "/" + run_name + "_iteration_" + std::to_string(it);
+            const std::string prefix = dirs[(size_t)(first + t)] + "/" + run_name + "_iteration_" + std::to_string(it);
             const int rc = format == 2 ? sprl_write_v2((prefix + ".sprl2").c_str(), &part) : sprl_write_npy(prefix.c_str(), &part);
             if (rc != 0) return fail("write");
         }
@@ -208,5 +217,18 @@ int main(int argc, char** argv) {
         sprl_records_free(&rec);
     }
     if (eng) sprl_engine_destroy(eng);
+    return 0;
+    };
+
+    if (populations == 1) return run_range(0, cover, 0);
+    std::vector<std::thread> threads;
+    std::vector<int> rcs((size_t)populations, 0);
+    for (int p = 0; p < populations; ++p) {
+        const int first = (int)((long long)cover * p / populations), last = (int)((long long)cover * (p + 1) / populations);
+        threads.emplace_back([&, p, first, last] { rcs[(size_t)p] = run_range(first, last - first, p); });
+    }
+    for (auto& t : threads) t.join();
+    for (int rc : rcs)
+        if (rc) return rc;
     return 0;
 }

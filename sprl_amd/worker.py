@@ -99,9 +99,37 @@ def write_task_files(lib, rec, games_per_task, dirs, run_name, iteration, fmt="v
 
 
 def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, concurrent_games=None, lib=None,
-               model_for_iteration=None, log=print, device=0, resign_threshold=0.0, resign_min_ply=0, fmt="v1"):
-    """The worker loop (GridWorker.hpp:111-197) for task ids [task_id, task_id + cover)."""
+               model_for_iteration=None, log=print, device=0, resign_threshold=0.0, resign_min_ply=0, fmt="v1", populations=1):
+    """The worker loop (GridWorker.hpp:111-197) for task ids [task_id, task_id + cover).  populations > 1 (as the native
+    worker's --populations): the covered tasks are split into that many ranges, each with its own engine on a private HIP
+    stream and its own host thread (the C calls release the GIL), RNG streams from disjoint ranges per population."""
     lib = lib or E.load_library()
+    if populations > 1:
+        import threading
+        if populations > cover:
+            raise ValueError("more populations than covered tasks")
+        seed = int(time.time_ns() & 0x7FFFFFFFFFFF) | 1 if seed is None else seed
+        errors = []
+
+        def one(p):
+            first, last = cover * p // populations, cover * (p + 1) // populations
+            try:
+                run_worker(consts, task_id + first, last - first, num_iters, root, seed,
+                           None if concurrent_games is None else -(-concurrent_games // populations), lib, model_for_iteration,
+                           log if p == 0 else (lambda *a, **k: None), device, resign_threshold, resign_min_ply, fmt,
+                           populations=-(p + 1))
+            except Exception as exc:  # noqa: BLE001 - reported to the caller below
+                errors.append(exc)
+
+        ths = [threading.Thread(target=one, args=(p,)) for p in range(populations)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+        return
+    pop = -populations - 1 if populations < 0 else -1                 # (internal: this call is population `pop` of several)
     num_iters = consts.num_iters if num_iters is None else num_iters
     seed = int(time.time_ns() & 0x7FFFFFFFFFFF) | 1 if seed is None else seed   # reference: random_device (Q3)
     dirs = [save_dir_for(consts, task_id + k, root) for k in range(cover)]
@@ -109,7 +137,7 @@ def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, co
         existed = os.path.isdir(d)
         os.makedirs(d, exist_ok=True)
         log(("Directory already exists: " if existed else "Created directory: ") + d)
-    next_stream = 1
+    next_stream = 1 + max(pop, 0) * (1 << 27)
     eng, eng_sig = None, None
     for it in range(num_iters):
         log(f"Starting iteration {it}...")
@@ -125,7 +153,8 @@ def run_worker(consts, task_id, cover=1, num_iters=None, root=".", seed=None, co
                 eng.close()
             cfg = E.default_config(consts.game, lib, device=device, concurrent_games=sig[3], num_traversals=trav, max_batch=mb,
                                    max_queue=mq, dir_eps=consts.dir_eps, dir_alpha=consts.dir_alpha, seed=seed,
-                                   stream_base=next_stream, resign_threshold=resign_threshold, resign_min_ply=resign_min_ply)
+                                   stream_base=next_stream, resign_threshold=resign_threshold, resign_min_ply=resign_min_ply,
+                                   own_stream=1 if pop >= 0 else 0)
             eng, eng_sig = E.Engine(cfg, lib), sig
         next_stream += total                        # (a kept engine continues its stream numbering itself)
         log("Using initial network..." if model == "random" else "Using traced PyTorch network...")
@@ -153,6 +182,8 @@ def main(argv=None):
                          "decision node after the search is below -threshold")
     ap.add_argument("--resign-min-ply", type=int, default=0)
     ap.add_argument("--format", default="v1", choices=["v1", "v2"], help="v1 = the reference's .npy triple; v2 = compact .sprl2")
+    ap.add_argument("--populations", type=int, default=1,
+                    help="split the covered tasks over this many engines on private HIP streams and host threads")
     try:
         args = ap.parse_args(argv)
     except SystemExit:
@@ -166,7 +197,8 @@ def main(argv=None):
         consts = WorkerConstants(**{**consts.__dict__, "run_name": args.run_name})
     print(f"Task {args.task_id} of {args.num_tasks}, covering {args.cover} task(s).")
     run_worker(consts, args.task_id, cover=args.cover, num_iters=args.num_iters, device=args.device, seed=args.seed,
-               resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply, fmt=args.format)
+               resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply, fmt=args.format,
+               populations=args.populations)
     return 0
 
 

@@ -615,6 +615,36 @@ def test_native_worker_two_iterations_with_model_handover(lib, tmp_path):
     assert (d1.view(np.uint32) == ora["dists"][split:].view(np.uint32)).all()
 
 
+def test_native_worker_two_populations_with_cnn(lib, tmp_path):
+    """sprl_worker --populations 2 on the GPU with the traced CNN from iteration 0 on: two engines on private streams driven
+    from two host threads.  Population 0's task files equal those of a single-engine worker covering the same tasks with the
+    same seed (the hand-written CNN gives a board the same bits in any batch), population 1's files are complete and valid."""
+    import subprocess
+    from sprl_amd.network import make_network, trace_to_file
+    exe = os.path.join(ROOT, "sprl_amd", "sprl_worker")
+    model = trace_to_file(make_network("othello", 2, 64, seed=5), str(tmp_path / "m.pt"), "othello")
+    common = ["othello", "0", "4", "--num-tasks-const", "4", "--num-groups", "2", "--num-iters", "1", "--init-games", "3",
+              "--init-traversals", "48", "--init-max-batch", "8", "--init-max-queue", "4", "--seed", "41", "--model-iter0", model]
+    a = subprocess.run([exe] + common + ["--cover", "2", "--root", str(tmp_path / "one"), "--run-name", "r"],
+                       capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stderr + a.stdout
+    b = subprocess.run([exe] + common + ["--cover", "4", "--populations", "2", "--root", str(tmp_path / "two"), "--run-name", "r"],
+                       capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr + b.stdout
+    for task in (0, 1):
+        for part in ("states", "distributions", "outcomes"):
+            fa = open(tmp_path / f"one/data/games/r/0/{task}/r_iteration_0_{part}.npy", "rb").read()
+            fb = open(tmp_path / f"two/data/games/r/0/{task}/r_iteration_0_{part}.npy", "rb").read()
+            assert fa == fb, (task, part)
+    for task in (2, 3):
+        d = tmp_path / f"two/data/games/r/1/{task}"
+        s = np.load(d / "r_iteration_0_states.npy")
+        p = np.load(d / "r_iteration_0_distributions.npy")
+        o = np.load(d / "r_iteration_0_outcomes.npy")
+        assert s.shape[1:] == (3, 8, 8) and p.shape == (s.shape[0], 65) and o.shape == (s.shape[0],) and s.shape[0] >= 3 * 8 * 8
+        assert np.allclose(p.sum(1), 1.0, atol=1e-4)
+
+
 def test_go19_full_budget_with_compaction_and_resign(lib):
     """BASELINE config 5 at its stated budget: Go 19x19, 1600 iterations/move, batch 16 / queue 8, whole games against the
     oracle.  First with node recycling off and small arenas (8000 nodes of 5.5 KiB), so the large-tree fallback - Cheney

@@ -60,6 +60,24 @@ def test_worker_covers_several_tasks_with_reference_file_layout(emu, tmp_path):
     assert (d2.view(np.uint32) == ora["dists"][split:].view(np.uint32)).all()
 
 
+def test_worker_populations_match_the_native_worker_scheme(emu, tmp_path):
+    """run_worker(populations=2): tasks split over two engines / host threads, population p on RNG streams from 1 + p * 2^27
+    (the same scheme as sprl_worker --populations, tests below)."""
+    consts = W.WorkerConstants("connect_four", "poprun", 2, 4, 1, 2, 30, 8, 4, 1, 20, 8, 4, 0.25, 0.5)
+    W.run_worker(consts, task_id=0, cover=4, root=str(tmp_path), seed=77, lib=emu, model_for_iteration=lambda it: "random",
+                 log=lambda *a: None, populations=2)
+    cfg = po.make_config(po.GAME_C4, 30, math_mode=po.MATH_PORTABLE)
+    for pop, tasks in ((0, (0, 1)), (1, (2, 3))):
+        ora = po.selfplay(cfg, 4, 77, 1 + pop * (1 << 27), True)
+        split = ora["offsets"][2]
+        for k, task in enumerate(tasks):
+            got = np.load(tmp_path / f"data/games/poprun/{task // 2}/{task}/poprun_iteration_0_distributions.npy")
+            want = ora["dists"][:split] if k == 0 else ora["dists"][split:]
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (pop, task)
+    with pytest.raises(ValueError):
+        W.run_worker(consts, task_id=0, cover=1, root=str(tmp_path), seed=1, lib=emu, populations=2)
+
+
 @pytest.mark.parametrize("game,kw", [("othello", dict(num_traversals=16)), ("c4", dict(num_traversals=16)),
                                      ("go", dict(num_traversals=20)),
                                      ("go9", dict(num_traversals=20)),        # 81 cells: 2 words per bit set
@@ -243,3 +261,27 @@ def test_native_worker_process_contract(tmp_path):
     ora = po.selfplay(po.make_config(po.GAME_OTHELLO, 24, math_mode=po.MATH_PORTABLE), 2, 5, 1, True)
     assert (d2_.view(np.uint32) == ora["dists"].view(np.uint32)).all() and (o2 == ora["outcomes"]).all()
     assert s2.shape == (len(ora["players"]), 3, 8, 8)
+
+
+def test_native_worker_populations(tmp_path):
+    """--populations 2: the covered tasks are split over two engines driven from two host threads (on the GPU: two private HIP
+    streams).  Population 0 plays its tasks on the RNG streams a single engine would have used, population 1 on its own
+    disjoint range - every file is there and holds exactly the oracle's games for those streams."""
+    exe = _native_worker()
+    out = subprocess.run([exe, "connect_four", "0", "4", "--cover", "4", "--populations", "2", "--num-tasks-const", "4",
+                          "--num-groups", "2", "--num-iters", "1", "--init-games", "2", "--init-traversals", "30",
+                          "--init-max-batch", "8", "--init-max-queue", "4", "--seed", "77", "--root", str(tmp_path),
+                          "--run-name", "poprun"], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr
+    cfg = po.make_config(po.GAME_C4, 30, math_mode=po.MATH_PORTABLE)
+    for pop, tasks in ((0, (0, 1)), (1, (2, 3))):
+        ora = po.selfplay(cfg, 4, 77, 1 + pop * (1 << 27), True)          # this population's 2 tasks x 2 games
+        split = ora["offsets"][2]
+        for k, task in enumerate(tasks):
+            d = tmp_path / "data" / "games" / "poprun" / str(task // 2) / str(task)
+            got = np.load(d / "poprun_iteration_0_distributions.npy")
+            want = ora["dists"][:split] if k == 0 else ora["dists"][split:]
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (pop, task)
+            assert np.load(d / "poprun_iteration_0_outcomes.npy").shape[0] == got.shape[0]
+    assert subprocess.run([exe, "connect_four", "0", "4", "--num-tasks-const", "4", "--cover", "2", "--populations", "3"],
+                          capture_output=True).returncode == 1               # more populations than covered tasks
