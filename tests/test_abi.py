@@ -162,3 +162,35 @@ template int snippet_{i}<OthelloNode>(int, int, int, int, float, float, int, std
         f.write_text(src)
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-variable",
                                "-I", os.path.join(ROOT, "include"), str(f)])
+
+
+def test_busy_time_union_of_overlapping_launch_intervals(tmp_path):
+    """sprl_amd/csrc/busy_log.h (bench.py's roofline accounting with several populations): the time with at least one launch
+    executing is the length of the union of the launch intervals; with disjoint intervals it equals their sum."""
+    src = tmp_path / "busy_test.cpp"
+    src.write_text(r'''
+#include "busy_log.h"
+#include <cstdio>
+#include <cmath>
+int main() {
+    busy::Log log;
+    double sum = 0.0;
+    // two streams: [0,2) [3,5) on one, [1,4) [10,11) on the other; a nested interval [3.5,3.6); an empty log first
+    if (log.union_ms(&sum) != 0.0 || sum != 0.0) return 1;
+    log.add({ 3.0, 5.0 }); log.add({ 0.0, 2.0 });
+    if (std::fabs(log.union_ms(&sum) - 4.0) > 1e-12 || std::fabs(sum - 4.0) > 1e-12) return 2;       // disjoint: union == sum
+    log.add(std::vector<std::pair<double, double>>{ { 1.0, 4.0 }, { 10.0, 11.0 }, { 3.5, 3.6 } });
+    const double u = log.union_ms(&sum);
+    if (std::fabs(u - 6.0) > 1e-12) return 3;              // [0,5) + [10,11)
+    if (std::fabs(sum - 8.1) > 1e-12) return 4;
+    log.reset();
+    if (log.union_ms(nullptr) != 0.0) return 5;
+    std::printf("ok\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "busy_test"
+    inc = os.path.join(ROOT, "sprl_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", inc, "-I", "/opt/rocm/include", "-o", str(exe), str(src),
+                           "-lpthread"])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "ok"
