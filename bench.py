@@ -363,21 +363,30 @@ def main():
         # 4 tiles x 36 positions x 64 x 64 multiply-adds (4x fewer than the direct 3x3 convolution).
         tiles = ((G["rows"] + 3) // 4) * ((G["cols"] + 3) // 4)
         flop_per_board = 2 * tiles * 36 * 64 * 64
-        flop = d["conv_boards"] * flop_per_board
+        fill = (d["nn_evals"] / d["nn_rows"]) if d.get("nn_rows") else 1.0     # host-batched path: rows padded to a bucket are not work
+        flop = d["conv_boards"] * min(1.0, fill) * flop_per_board
         conv_time_ms = M["conv_busy"] if (mp > 1 and M["conv_busy"]) else d["conv_ms"]
         tf = flop / (conv_time_ms * 1e-3) / 1e12
         ctraffic = None
+        boards_per_launch = d["conv_boards"] / max(1, d["conv_launches"])
         cpath = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
-        if os.path.exists(cpath) and mp == 1:                   # measured per launch of one population's full-size batch
+        if os.path.exists(cpath) and args.game == "othello":
+            # PMC passes (separate rocprofv3 runs with one population, tools/profile_round.sh): HBM bytes per launch at the
+            # profiled boards per launch; the kernel's traffic is proportional to the boards of a launch (0.99 x algorithmic)
             with open(cpath) as tf_:
-                ctraffic = json.load(tf_).get("hbm_bytes_per_launch")
-        conv = {"bound": "mfma", "kernel": "wino_conv64 (3x3 conv 64->64 + BN/residual/ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
+                cj = json.load(tf_)
+            ctraffic = cj.get("hbm_bytes_per_launch")
+            if ctraffic and cj.get("boards_per_launch"):
+                ctraffic = ctraffic * boards_per_launch / cj["boards_per_launch"]
+        conv = {"bound": "mfma", "kernel": ("wino_conv64 (3x3 conv 64->64 + BN/residual/ReLU, Winograd F(4x4,3x3) on fp32 MFMA)"
+                                            if G["rows"] <= 8 and G["cols"] <= 8 else
+                                            "wino_conv64_nchw (any-board 3x3 conv 64->64 + BN/residual/ReLU, Winograd F(4x4,3x3) on fp32 MFMA)"),
                 "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                 "traffic": ctraffic, "share_of_step_time": conv_time_ms * 1e-3 / M["elapsed"],
                 "launch_ms_sum": d["conv_ms"], "busy_ms": M["conv_busy"],
                 "overlap": (M["conv_sum"] / M["conv_busy"]) if M["conv_busy"] else None,
                 "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
-                "boards_per_launch": d["conv_boards"] / max(1, d["conv_launches"]),
+                "boards_per_launch": boards_per_launch,
                 "flop_per_board": flop_per_board,
                 "direct_conv_equivalent_tflops": tf * 4.0, "populations": mp}
         return conv, tree

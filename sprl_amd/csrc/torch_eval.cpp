@@ -317,14 +317,28 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
             ya = nchw_act(x.size(0), H0, W0, x.options());
             za = nchw_act(x.size(0), H0, W0, x.options());
         }
+        // profile mode: HIP event pairs around every trunk-convolution launch, as in forward_wino
+        auto timed_conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
+                              at::Tensor& dst) {
+            const int B0 = (int)src.size(0);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+            if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
+            const int rc = sprl_wino_conv64_nchw(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res,
+                                                 dst.data_ptr<float>(), B0, H0, W0, 1, stream);
+            if (timed) {
+                (void)hipEventRecord(e1, (hipStream_t)stream);
+                prof->ev.push_back(e0);
+                prof->ev.push_back(e1);
+                prof->launches++;
+                prof->boards += B0;
+                if (prof->ev.size() >= 8192) prof->resolve();
+            }
+            return rc == 0;
+        };
         for (const auto& b : n.blocks) {
             if (trunk_wino) {
-                const int B0 = (int)x.size(0);
-                if (sprl_wino_conv64_nchw(x.data_ptr<float>(), b.u1.data_ptr<float>(), b.s1.data_ptr<float>(), b.t1.data_ptr<float>(),
-                                          nullptr, ya.data_ptr<float>(), B0, H0, W0, 1, stream) != 0 ||
-                    sprl_wino_conv64_nchw(ya.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(), b.t2.data_ptr<float>(),
-                                          x.data_ptr<float>(), za.data_ptr<float>(), B0, H0, W0, 1, stream) != 0)
-                    return false;
+                if (!timed_conv(x, b.u1, b.s1, b.t1, nullptr, ya) || !timed_conv(ya, b.u2, b.s2, b.t2, x.data_ptr<float>(), za)) return false;
                 std::swap(x, za);
                 continue;
             }
