@@ -258,8 +258,8 @@ int launch_records_expand(int game, const EngineParams& P, const RecExpanded& ou
 }
 
 void* mark() {
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    hipEvent_t e = busy::get_event();                  // pooled per host thread
+    if (!e) return nullptr;
     (void)hipEventRecord(e, g_stream);
     return (void*)e;
 }
@@ -269,9 +269,7 @@ double elapsed_ms(void* a, void* b) {
     (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b);
     return (double)ms;
 }
-void mark_free(void* m) {
-    if (m) (void)hipEventDestroy((hipEvent_t)m);
-}
+void mark_free(void* m) { busy::put_event((hipEvent_t)m); }
 
 static busy::Log g_tree_busy;
 void* chain_new() { return new busy::Chain(); }
@@ -284,7 +282,7 @@ double resolve_logged(void* chain, void* a, void* b) {
     double ms = 0.0;
     (void)hipEventSynchronize((hipEvent_t)b);
     const auto iv = static_cast<busy::Chain*>(chain)->resolve((hipEvent_t)a, (hipEvent_t)b, &ms);
-    (void)hipEventDestroy((hipEvent_t)b);
+    busy::put_event((hipEvent_t)b);
     g_tree_busy.add(iv);
     return ms;
 }

@@ -79,7 +79,7 @@ struct ConvProfile {
             (void)hipEventSynchronize(ev[i + 1]);
             iv.push_back(chain.resolve(ev[i], ev[i + 1], &t));
             ms += t;
-            (void)hipEventDestroy(ev[i + 1]);
+            busy::put_event(ev[i + 1]);
         }
         ev.clear();
         g_conv_busy.add(iv);
@@ -209,7 +209,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
     auto conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
                     at::Tensor& dst) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
         if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
         const int rc = sprl_wino_conv64_dev(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(),
                                             res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, stream);
@@ -232,7 +232,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
         if (!conv(x, b.u1, b.s1, b.t1, nullptr, y)) return false;
         if (fuse_last && bi + 1 == n.blocks.size()) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+            const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
             if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
             // last convolution + both head convolutions in one kernel (the trunk output is never written), then the FC layers
             at::Tensor maps = mdl->maps;
@@ -322,7 +322,7 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
                               at::Tensor& dst) {
             const int B0 = (int)src.size(0);
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            const bool timed = prof && prof->on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+            const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
             if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
             const int rc = sprl_wino_conv64_nchw(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res,
                                                  dst.data_ptr<float>(), B0, H0, W0, 1, stream);
