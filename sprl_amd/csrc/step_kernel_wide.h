@@ -37,6 +37,7 @@ template <class G>
 struct WaveLdsW {
     uint32_t path[G::MAX_DEPTH];
     Bits<G::WORDS> hist[G::HIST_CAP][2];
+    uint64_t hsig[G::HIST_CAP];               // pos_sig of hist[i]: the superko test compares signatures first
     Bits<G::WORDS> leaf_hist[SPRL_MAXQ][G::HIST][2];
     uint32_t leaf_size[SPRL_MAXQ];
     float xf[G::STRIPS * 64];                 // cross-strip exchange: one float / u32 / group mask per point
@@ -45,6 +46,26 @@ struct WaveLdsW {
     Bits<G::WORDS> xg[G::STRIPS * 64];
     uint32_t fcache[SPRL_FCACHE];             // recycled node ids ready for reuse (GameCtl::fcache while the slot runs)
 };
+
+// 64-bit signature of a position (xor of rotated words): equal positions have equal signatures, so the positional-superko test
+// only has to compare whole bit sets (2 x WORDS words) with the ancestors whose signature matches the candidate's - exact as
+// before, ~WORDS times fewer LDS reads and compares per ancestor.
+template <int W>
+SPRL_DEV uint64_t pos_sig(const Bits<W>& a, const Bits<W>& b) {
+    uint64_t s = 0;
+    for (int w = 0; w < W; ++w) {
+        const int r0 = (11 * w + 1) & 63, r1 = (11 * w + 33) & 63;
+        s ^= (a.w[w] << r0) | (a.w[w] >> (64 - r0));
+        s ^= (b.w[w] << r1) | (b.w[w] >> (64 - r1));
+    }
+    return s;
+}
+template <class G>
+SPRL_DEV void hist_put(WaveLdsW<G>* lds, int at, const Bits<G::WORDS>& p0, const Bits<G::WORDS>& p1) {      // one lane calls this
+    lds->hist[at][0] = p0;
+    lds->hist[at][1] = p1;
+    lds->hsig[at] = pos_sig<G::WORDS>(p0, p1);
+}
 
 template <class G> SPRL_DEV uint8_t* node_at(uint8_t* abase, uint32_t idx) { return abase + (size_t)idx * G::NODE_BYTES; }
 template <class G> SPRL_DEV float* rowN(uint8_t* n) { return (float*)n; }
@@ -226,7 +247,9 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>
             const BB nown = own | BB::bit(a), nopp = opp & ~cap;
             const BB np0 = c.player ? nopp : nown, np1 = c.player ? nown : nopp;
             bool repeat = false;
-            for (int i = 0; i < n_hist; ++i) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
+            const uint64_t sg = pos_sig<G::WORDS>(np0, np1);
+            for (int i = 0; i < n_hist; ++i)
+                if (lds->hsig[i] == sg) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
             ok = has_libs && !repeat;
         }
         const uint64_t m = wv::ballot(ok);
@@ -334,7 +357,9 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds,
             const BB nown = own | BB::bit(a), nopp = opp & ~cap;
             const BB np0 = c.player ? nopp : nown, np1 = c.player ? nown : nopp;
             bool repeat = false;
-            for (int i = 0; i < n_hist; ++i) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
+            const uint64_t sg = pos_sig<G::WORDS>(np0, np1);
+            for (int i = 0; i < n_hist; ++i)
+                if (lds->hsig[i] == sg) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
             ok = has_libs && !repeat;
         }
         const uint64_t m = wv::ballot(ok);
@@ -347,10 +372,7 @@ template <class G>
 SPRL_DEV void make_child(GameW& g, WaveLdsW<G>* lds, const PosW<G::WORDS>& parent, int action, int at,
                          PosW<G::WORDS>& cs) {
     G::apply(parent, action, cs);
-    if (wv::lane() == 0) {
-        lds->hist[at][0] = cs.p0;
-        lds->hist[at][1] = cs.p1;
-    }
+    if (wv::lane() == 0) hist_put<G>(lds, at, cs.p0, cs.p1);
     wv::sync();
     if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, at + 1, g.legal_form);
 }
@@ -541,10 +563,7 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
         g.rootW -= 1.0f;
         int depth = 0;
         NodeHdrW<G::WORDS> h = load_hdr<G>(node_at<G>(g.abase, cur));
-        if (l == 0) {
-            lds->hist[g.ply][0] = h.p0;
-            lds->hist[g.ply][1] = h.p1;
-        }
+        if (l == 0) hist_put<G>(lds, g.ply, h.p0, h.p1);
         while (h.exp_epoch == g.epoch && !(h.flags & F_TERMINAL)) {
             uint8_t* np = node_at<G>(g.abase, cur);
             float n[WS], w[WS], score[WS];
@@ -633,10 +652,7 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
                 break;
             }
             h = load_hdr<G>(node_at<G>(g.abase, cur));
-            if (l == 0) {
-                lds->hist[g.ply + depth][0] = h.p0;
-                lds->hist[g.ply + depth][1] = h.p1;
-            }
+            if (l == 0) hist_put<G>(lds, g.ply + depth, h.p0, h.p1);
         }
         if (h.flags & F_TERMINAL) {
             const float value = h.winner < 0 ? 0.0f : (h.winner == (int8_t)h.player ? 1.0f : -1.0f);
@@ -770,10 +786,7 @@ SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>*
     g.traversals = 0;
     g.n_leaves = 0;
     g.d_created++;
-    if (wv::lane() == 0) {
-        lds->hist[0][0] = s.p0;
-        lds->hist[0][1] = s.p1;
-    }
+    if (wv::lane() == 0) hist_put<G>(lds, 0, s.p0, s.p1);
     Bits<G::WORDS>* gh = (Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
     gh[0] = s.p0;
     gh[1] = s.p1;
@@ -897,10 +910,7 @@ SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* l
     g.ply += 1;
     {
         const NodeHdrW<G::WORDS> nh = load_hdr<G>(node_at<G>(g.abase, c));
-        if (l == 0) {
-            lds->hist[g.ply][0] = nh.p0;
-            lds->hist[g.ply][1] = nh.p1;
-        }
+        if (l == 0) hist_put<G>(lds, g.ply, nh.p0, nh.p1);
         Bits<G::WORDS>* gh = (Bits<G::WORDS>*)P.hist_boards + ((size_t)slot * G::HIST_CAP + (size_t)g.ply) * 2;
         gh[0] = nh.p0;
         gh[1] = nh.p1;
@@ -941,10 +951,7 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
     wv::sync();
     if (g.status == ST_ACTIVE) {
         const Bits<G::WORDS>* gh = (const Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
-        for (int i = wv::lane(); i <= g.ply; i += 64) {
-            lds->hist[i][0] = gh[2 * i];
-            lds->hist[i][1] = gh[2 * i + 1];
-        }
+        for (int i = wv::lane(); i <= g.ply; i += 64) hist_put<G>(lds, i, gh[2 * i], gh[2 * i + 1]);
         wv::sync();
     }
     if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);
