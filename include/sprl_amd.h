@@ -61,7 +61,7 @@ typedef struct sprl_config {
     int32_t mask_frame;        /* SPRL_MASK_* */
     int32_t node_cap;          /* nodes per game arena (1 KiB each; Go 9x9 2 KiB, 19x19 5.5 KiB); 0 = default.  Othello / Connect Four /
                                   Go 7x7: < 2^24 (child indices widen from 16 to 24 bits above 65535), nodes of pruned siblings are
-                                  reused, default 4 x num_traversals + 1024.  Boards wider than 8x8: <= 65535 */
+                                  reused, default min(4 x, 2 x + 4096) num_traversals + 1024.  Boards wider than 8x8: <= 65535 */
     int32_t spare_arenas;      /* arenas kept free for compaction; 0 = default */
     int32_t max_plies;         /* record capacity per game; 0 = default */
     uint64_t seed;             /* game g uses Random(seed, stream_base + g) (utils/random.hpp:92-103); a later run on the same
@@ -75,6 +75,8 @@ typedef struct sprl_config {
                                   -resign_threshold; the ply's sample is kept, the opponent wins */
     int32_t resign_min_ply;    /* no resignation before this ply */
     int32_t no_recycle;        /* 1: never reuse the nodes of pruned siblings (bump allocation + compaction only; tests) */
+    int32_t alloc_base;        /* 0 = default.  Tests: every game starts allocating at this node id, so that a short game's ids
+                                  cross the 16-bit boundary (single-strip kernels, alloc_base + max_batch + 8 < node_cap) */
 } sprl_config;
 
 /* Fills `cfg` with the reference worker's constants for `game` (OTHWorker.cpp:24-28, C4Worker.cpp:23-27,
@@ -201,8 +203,9 @@ int sprl_records_expand_boards(const sprl_records* r, int8_t* boards, int8_t* pl
  * _outcomes.npy (byte-identical headers; temp file + rename, outcomes last). */
 int sprl_write_npy(const char* path_prefix, const sprl_records* r);
 
-/* A view of games [first_game, first_game + num_games) of `r` (no copy; valid while `r` is; sprl_records_free on it is a
- * no-op): one GPU run covers several reference tasks, each task's games go to its own directory (sprl_worker --cover). */
+/* A view of games [first_game, first_game + num_games) of `r` (the samples are not copied; valid while `r` is): one GPU run
+ * covers several reference tasks, each task's games go to its own directory (sprl_worker --cover).  The view owns only its
+ * rebased ply offsets: release it with sprl_records_free, which leaves `r` untouched. */
 int sprl_records_slice(const sprl_records* r, int32_t first_game, int32_t num_games, sprl_records* out);
 
 /* Compact record file (NOT a reference format): "SPRLv2\1\0", int64 size, then the packed wire format

@@ -15,14 +15,26 @@ LIB_TORCH = os.path.join(HERE, "_ref", "libsprl_ref_torch.so")
 # the same torch-free slice with games/GoNode.hpp's GO_BOARD_WIDTH / GO_KOMI set to 9 / 7.5 (oracle/Makefile: ref_go9);
 # its ref_go_* entry points play 9x9 Go, everything else is identical to LIB
 LIB_GO9 = os.path.join(HERE, "_ref", "libsprl_ref_go9.so")
+# ... and at 19 / 7.5 with Coord / LibertyCount widened to int16_t (games/GoNode.hpp:36-37; oracle/Makefile: ref_go19)
+LIB_GO19 = os.path.join(HERE, "_ref", "libsprl_ref_go19.so")
+GO_VARIANTS = {"go9": (LIB_GO9, 9), "go19": (LIB_GO19, 19)}
 
 GEOM = {"othello": dict(cells=64, A=65, nsym=8, hist=1), "c4": dict(cells=42, A=7, nsym=2, hist=1),
-        "go": dict(cells=49, A=50, nsym=8, hist=8), "go9": dict(cells=81, A=82, nsym=8, hist=8)}
+        "go": dict(cells=49, A=50, nsym=8, hist=8), "go9": dict(cells=81, A=82, nsym=8, hist=8),
+        "go19": dict(cells=361, A=362, nsym=8, hist=8)}
+
+
+def _variant(game):
+    return game if game in GO_VARIANTS else None
+
+
+def _fn(game):
+    return "go" if game in GO_VARIANTS else game
 
 
 def available(torch=False, variant=None):
-    if variant == "go9":
-        return os.path.exists(LIB_GO9)
+    if variant in GO_VARIANTS:
+        return os.path.exists(GO_VARIANTS[variant][0])
     return os.path.exists(LIB_TORCH if torch else LIB)
 
 
@@ -34,9 +46,9 @@ def lib(torch=False, variant=None):
     if key not in _libs:
         if torch:
             import torch as _t  # noqa: F401  (loads libtorch so the harness' DT_NEEDED entries resolve)
-        L = C.CDLL(LIB_GO9 if variant == "go9" else (LIB_TORCH if torch else LIB))
-        if variant == "go9":
-            assert L.ref_go_board_width() == 9
+        L = C.CDLL(GO_VARIANTS[variant][0] if variant in GO_VARIANTS else (LIB_TORCH if torch else LIB))
+        if variant in GO_VARIANTS:
+            assert L.ref_go_board_width() == GO_VARIANTS[variant][1]
         L.ref_seed.argtypes = [C.c_uint64, C.c_int]
         L.ref_uniform_int.argtypes = [C.c_int, C.c_int]
         L.ref_uniform_float.restype = C.c_float
@@ -83,8 +95,8 @@ def vp(a):
 def selfplay(game, eval_kind, num_games, traversals, max_batch, max_queue, eps, alpha, seed, stream_base=1,
              per_game_stream=True, use_sym=1, add_noise=1, model_path=None):
     g = GEOM[game]
-    variant = "go9" if game == "go9" else None
-    fn_game = "go" if game == "go9" else game
+    variant = _variant(game)
+    fn_game = _fn(game)
     cap = num_games * (2 * g["cells"] + 8 if fn_game == "go" else 130) * (g["nsym"] if use_sym else 1)
     boards = np.zeros((cap, g["hist"] * g["cells"]), np.int8)
     players = np.zeros(cap, np.int8)
@@ -117,7 +129,7 @@ def search_trace(game, eval_kind, moves, traversals, max_batch, max_queue, eps, 
     stats = np.zeros((moves, 3, g["A"]), np.float32)
     trav = np.zeros(moves, np.int32)
     chosen = np.zeros(moves, np.int16)
-    m = getattr(lib(variant="go9" if game == "go9" else None), f"ref_{'go' if game == 'go9' else game}_search_trace")(eval_kind, moves, traversals, max_batch, max_queue, eps, alpha,
+    m = getattr(lib(variant=_variant(game)), f"ref_{_fn(game)}_search_trace")(eval_kind, moves, traversals, max_batch, max_queue, eps, alpha,
                                                    use_sym, add_noise, seed, stream, vp(stats), vp(trav), vp(chosen))
     return stats[:m], trav[:m], chosen[:m]
 
@@ -130,7 +142,7 @@ def playout(game, seed, stream=1, max_plies=200):
     masks = np.zeros((max_plies, g["A"]), np.float32)
     terminal = np.zeros(max_plies, np.int8)
     rewards = np.zeros((max_plies, 2), np.float32)
-    n = getattr(lib(variant="go9" if game == "go9" else None), f"ref_{'go' if game == 'go9' else game}_playout")(seed, stream, max_plies, vp(boards), vp(players), vp(actions),
+    n = getattr(lib(variant=_variant(game)), f"ref_{_fn(game)}_playout")(seed, stream, max_plies, vp(boards), vp(players), vp(actions),
                                               vp(masks), vp(terminal), vp(rewards))
     return dict(boards=boards[:n], players=players[:n], actions=actions[:n], masks=masks[:n],
                 terminal=terminal[:n], rewards=rewards[:n])

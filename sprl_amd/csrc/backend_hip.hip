@@ -258,7 +258,7 @@ int launch_records_expand(int game, const EngineParams& P, const RecExpanded& ou
 }
 
 void* mark() {
-    hipEvent_t e = busy::get_event();                  // pooled per host thread
+    hipEvent_t e = busy::get_event();                  // pooled per process and device
     if (!e) return nullptr;
     (void)hipEventRecord(e, g_stream);
     return (void*)e;

@@ -58,32 +58,84 @@ inline hipEvent_t base() {
 }
 
 // Events are reused: creating and destroying two of them around every launch costs host time on the enqueue path (measured:
-// together with the rest of the profile mode 4 % of the bench's games/s).  One pool per host thread, no locking.
-inline std::vector<hipEvent_t>& pool() {
-    static thread_local std::vector<hipEvent_t> p;
-    return p;
+// together with the rest of the profile mode 4 % of the bench's games/s).  ONE pool per process, keyed by device and guarded
+// by a mutex (an uncontended lock is tens of nanoseconds; hipEventCreate is microseconds): engines are driven from short-lived
+// host threads (bench.py / sprl_worker --populations start fresh threads per step), so a per-thread pool would be empty on
+// every new thread and would leak what it held when the thread ends.  The pool is emptied when the last owner (Chain) of the
+// process goes away.
+struct Pool {
+    std::mutex mu;
+    std::vector<std::pair<int, std::vector<hipEvent_t>>> by_dev;   // a handful of devices at most: linear search
+    int owners = 0;
+    std::vector<hipEvent_t>& of(int dev) {
+        for (auto& p : by_dev)
+            if (p.first == dev) return p.second;
+        by_dev.emplace_back(dev, std::vector<hipEvent_t>());
+        return by_dev.back().second;
+    }
+    void drain() {                                  // caller holds mu
+        for (auto& p : by_dev) {
+            for (hipEvent_t e : p.second) (void)hipEventDestroy(e);
+            p.second.clear();
+        }
+    }
+};
+inline Pool& pool() {
+    static Pool* p = new Pool();                    // never destroyed: other static destructors may still return events
+    return *p;
 }
+inline int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+// an event of the CURRENT device (the caller has bound its engine's / model's device)
 inline hipEvent_t get_event() {
-    auto& p = pool();
-    if (!p.empty()) {
-        hipEvent_t e = p.back();
-        p.pop_back();
-        return e;
+    Pool& P = pool();
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto& v = P.of(dev);
+        if (!v.empty()) {
+            hipEvent_t e = v.back();
+            v.pop_back();
+            return e;
+        }
     }
     hipEvent_t e = nullptr;
     return hipEventCreate(&e) == hipSuccess ? e : nullptr;
 }
+// returns an event obtained with get_event on the current device
 inline void put_event(hipEvent_t e) {
     if (!e) return;
-    auto& p = pool();
-    if (p.size() < 65536) p.push_back(e);
-    else (void)hipEventDestroy(e);
+    Pool& P = pool();
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto& v = P.of(dev);
+        if (P.owners > 0 && v.size() < 65536) {
+            v.push_back(e);
+            return;
+        }
+    }
+    (void)hipEventDestroy(e);
 }
 
 // One per owner (engine or model): turns its event pairs into intervals on the process clock.
 struct Chain {
     hipEvent_t ref = nullptr;     // an already resolved event of this owner (or base()); owned unless it is base()
     double ref_ms = 0.0;
+    Chain() {
+        std::lock_guard<std::mutex> g(pool().mu);
+        ++pool().owners;
+    }
+    Chain(const Chain&) = delete;
+    Chain& operator=(const Chain&) = delete;
+    ~Chain() {
+        release();
+        std::lock_guard<std::mutex> g(pool().mu);
+        if (--pool().owners == 0) pool().drain();
+    }
     // both events have completed; takes ownership of `start` (kept as the next reference), the caller destroys `end`
     std::pair<double, double> resolve(hipEvent_t start, hipEvent_t end, double* dur_ms) {
         if (!ref) { ref = base(); ref_ms = 0.0; }

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -358,18 +359,26 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.num_spare = cfg->spare_arenas > 0 ? cfg->spare_arenas : (cfg->concurrent_games / 64 > 8 ? cfg->concurrent_games / 64 : 8);
     // Node recycling (single-strip kernel): an arena holds the live subtree + the garbage not yet reused, so its size follows
     // the per-move budget, not the game length.  High-water marks measured over whole games: Othello @800 1 291 nodes,
-    // Connect Four @512 673, Go 7x7 @400 487 - 4 x traversals + 1024 leaves a 3-5x margin; compaction
-    // into a spare arena remains the fallback.  Boards wider than 8x8 (multi-strip kernel): the same, with 16-bit child indices.
+    // Connect Four @512 673, Go 7x7 @400 487, maximum over 4096 Othello games @800 2 261 - 4 x traversals
+    // + 1024 leaves a 2-5x margin at the steady-state budgets.  The margin a tree needs does not grow with the budget (the
+    // high-water mark stays near 1.6 x traversals), so above 2048 traversals the default is 2 x + 4096 + 1024: the reference's
+    // iteration-0 budgets (131 072 / 262 144 traversals per move, OTHWorker.cpp:17, GoWorker.cpp:17) then take 0.26 / 0.5 GiB
+    // per game instead of 0.5 / 1 GiB; compaction into a spare arena remains the fallback.  Boards wider than 8x8 (multi-strip kernel): the same, with 16-bit child indices.
     P.recycle = (cfg->max_batch + 2 <= SPRL_FCACHE && !cfg->no_recycle) ? 1 : 0;
     long cap = cfg->node_cap > 0 ? cfg->node_cap
-               : P.recycle     ? (long)cfg->num_traversals * 4 + 1024
+               : P.recycle     ? std::min((long)cfg->num_traversals * 4, (long)cfg->num_traversals * 2 + 4096) + 1024
                                : (long)cfg->num_traversals * 52 + 1024;
     if (!single_strip && cap > 65535) cap = 65535;
     if (cap > 0xFFFFFE) cap = 0xFFFFFE;
     if (cap < cfg->max_batch + 8) cap = cfg->max_batch + 8;
     P.node_cap = (int)cap;
-    if (const char* ab = getenv("SPRL_TEST_ALLOC_BASE"))   // test hook: games start allocating here (crosses the 16-bit boundary early)
-        if (single_strip && atol(ab) > 0 && atol(ab) + cfg->max_batch + 8 < cap) P.alloc_base = (uint32_t)atol(ab);
+    if (cfg->alloc_base != 0) {                         // tests: games start allocating here (crosses the 16-bit boundary early)
+        if (!single_strip || cfg->alloc_base < 0 || (long)cfg->alloc_base + cfg->max_batch + 8 >= cap) {
+            sprl_engine_destroy(e);
+            return fail(SPRL_E_CONFIG, "alloc_base needs a single-strip game and alloc_base + max_batch + 8 < node_cap");
+        }
+        P.alloc_base = (uint32_t)cfg->alloc_base;
+    }
     P.wide_idx = cap > 65535 ? 1 : 0;                 // child indices: u16 row, + a u8 row above 65535 nodes
     P.none_idx = P.wide_idx ? SPRL_NONE24 : SPRL_NONE16;
     P.max_plies = cfg->max_plies > 0 ? cfg->max_plies : e->g.default_max_plies;

@@ -179,14 +179,13 @@ int main(int argc, char** argv) {
         const int mb = it == 0 ? k.init_max_batch : k.max_batch, mq = it == 0 ? k.init_max_queue : k.max_queue;
         const int total = games * cover;
         const int conc_cap = concurrent > 0 ? (concurrent + populations - 1) / populations : 0;
-        const int conc = conc_cap > 0 && conc_cap < total ? conc_cap : total;
+        int conc = conc_cap > 0 && conc_cap < total ? conc_cap : total;
         if (!eng || eng_sig[0] != trav || eng_sig[1] != mb || eng_sig[2] != mq || eng_sig[3] != conc) {
             if (eng) sprl_engine_destroy(eng);
             eng = nullptr;
             sprl_config cfg;
             if (sprl_config_default(k.game, &cfg) != 0) return fail("config");
             cfg.device = device;
-            cfg.concurrent_games = conc;
             cfg.num_traversals = trav;
             cfg.max_batch = mb;
             cfg.max_queue = mq;
@@ -197,8 +196,20 @@ int main(int argc, char** argv) {
             cfg.own_stream = populations > 1 ? 1 : 0;
             cfg.resign_threshold = resign;
             cfg.resign_min_ply = resign_min_ply;
-            if (sprl_engine_create(&cfg, &eng) != 0) return fail("engine");
-            eng_sig[0] = trav; eng_sig[1] = mb; eng_sig[2] = mq; eng_sig[3] = conc;
+            // The iteration-0 budgets (131 072 / 262 144 traversals per move) need 0.26 - 0.5 GiB of node arena per resident game:
+            // when the games of all covered tasks do not fit into HBM together, keep fewer of them resident (the engine starts
+            // the next game in a slot as soon as one ends) instead of giving up.
+            const int wanted = conc;
+            int rc = 0;
+            for (;;) {
+                cfg.concurrent_games = conc;
+                rc = sprl_engine_create(&cfg, &eng);
+                if (rc != SPRL_E_DEVICE || conc <= 1 || !strstr(sprl_last_error(), "allocation")) break;
+                conc = (conc + 1) / 2;
+            }
+            if (rc != 0) return fail("engine");
+            if (conc != wanted) printf("HBM holds %d of the %d games at once; the rest start as slots free up.\n", conc, wanted);
+            eng_sig[0] = trav; eng_sig[1] = mb; eng_sig[2] = mq; eng_sig[3] = wanted;
         }
         next_stream += total;                // (an engine kept from the previous iteration continues its stream numbering itself)
         printf(model == "random" || model == "heuristic" ? "Using initial network...\n" : "Using traced PyTorch network...\n");
@@ -207,10 +218,17 @@ int main(int argc, char** argv) {
         if (sprl_engine_run(eng, total, &rec) != 0) return fail("self-play");
         for (int t = 0; t < cover; ++t) {
             sprl_records part;
-            if (sprl_records_slice(&rec, t * games, games, &part) != 0) return fail("slice");
+            if (sprl_records_slice(&rec, t * games, games, &part) != 0) {
+                sprl_records_free(&rec);
+                return fail("slice");
+            }
             const std::string prefix = dirs[(size_t)(first + t)] + "/" + run_name + "_iteration_" + std::to_string(it);
             const int rc = format == 2 ? sprl_write_v2((prefix + ".sprl2").c_str(), &part) : sprl_write_npy(prefix.c_str(), &part);
-            if (rc != 0) return fail("write");
+            sprl_records_free(&part);                        // the view owns its rebased offsets (include/sprl_amd.h)
+            if (rc != 0) {
+                sprl_records_free(&rec);
+                return fail("write");
+            }
         }
         printf("%d games played, %lld states collected.\n", total, (long long)sprl_records_num_samples(&rec));   // SelfPlay.hpp:241
         fflush(stdout);

@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("use_symmetry", C.c_int32), ("add_noise", C.c_int32), ("mask_frame", C.c_int32), ("node_cap", C.c_int32),
         ("spare_arenas", C.c_int32), ("max_plies", C.c_int32), ("seed", C.c_uint64), ("stream_base", C.c_int32),
         ("profile", C.c_int32), ("own_stream", C.c_int32), ("resign_threshold", C.c_float),
-        ("resign_min_ply", C.c_int32), ("no_recycle", C.c_int32),
+        ("resign_min_ply", C.c_int32), ("no_recycle", C.c_int32), ("alloc_base", C.c_int32),
     ]
 
 
@@ -233,6 +233,10 @@ class Engine:
         buf = io.BytesIO()
         torch.jit.save(traced, buf)
         raw = buf.getvalue()
+        self._check(self._lib.sprl_engine_set_model_buffer(self._h, raw, len(raw)))
+
+    def set_model_bytes(self, raw: bytes):
+        """Hot swap from a TorchScript archive already in memory (network.trace_to_bytes)."""
         self._check(self._lib.sprl_engine_set_model_buffer(self._h, raw, len(raw)))
 
     def set_forward(self, fn):

@@ -87,12 +87,23 @@ def make_network(game: str, num_blocks: int = 2, num_channels: int = 64, seed: i
     return net.eval()
 
 
-def trace_to_file(net: nn.Module, path: str, game: str) -> str:
-    """`torch.jit.trace` + save, like the reference controller does after each training iteration
-    (scripts/othello_controller.py:237-239, tracer.py:10-19): CPU weights, example randn(1, 2H+1, R, C)."""
+def _trace(net: nn.Module, game: str):
     rows, cols, _, hist = GAME_SHAPES[game]
     example = torch.randn(1, 2 * hist + 1, rows, cols)
     with torch.no_grad():
-        traced = torch.jit.trace(net.cpu().eval(), example)
-    traced.save(path)
+        return torch.jit.trace(net.cpu().eval(), example)
+
+
+def trace_to_file(net: nn.Module, path: str, game: str) -> str:
+    """`torch.jit.trace` + save, like the reference controller does after each training iteration
+    (scripts/othello_controller.py:237-239, tracer.py:10-19): CPU weights, example randn(1, 2H+1, R, C)."""
+    _trace(net, game).save(path)
     return path
+
+
+def trace_to_bytes(net: nn.Module, game: str) -> bytes:
+    """The same TorchScript archive in memory (for sprl_engine_set_model_buffer): no file is written or read."""
+    import io
+    buf = io.BytesIO()
+    torch.jit.save(_trace(net, game), buf)
+    return buf.getvalue()

@@ -19,7 +19,7 @@ import torch
 
 from . import engine as E
 from . import trainer as T
-from .network import GAME_SHAPES, GridResNet, trace_to_file
+from .network import GAME_SHAPES, GridResNet
 
 ENGINE_GAME = {"othello": "othello", "connect_four": "connect_four", "go7": "go7", "go9": "go9", "go19": "go19"}
 
@@ -59,10 +59,12 @@ class SelfPlayTrainLoop:
         self.net = GridResNet(rows, cols, actions, hist, cfg.num_blocks, cfg.num_channels)
         self.train_device = train_device or (f"cuda:{cfg.device}" if torch.cuda.is_available() else "cpu")
         self.window = T.ReplayWindow(self.tcfg, self.train_device)
-        self.root = cfg.root or tempfile.mkdtemp(prefix="sprl_loop_")
-        os.makedirs(os.path.join(self.root, "data", "models", cfg.run_name), exist_ok=True)
-        self.model_path = None                      # the traced file of the last iteration (kept for the reference tooling)
-        self.traced = None                          # None = iteration 0: the built-in initial evaluator ("random")
+        self.root = cfg.root or (tempfile.mkdtemp(prefix="sprl_loop_") if cfg.write_files else None)
+        if cfg.write_files:
+            os.makedirs(os.path.join(self.root, "data", "models", cfg.run_name), exist_ok=True)
+        self.model_path = None                      # write_files only: the traced file of the last iteration (reference tooling)
+        self.traced = None                          # None = iteration 0: the built-in initial evaluator ("random"); afterwards
+                                                    # the TorchScript archive of the last trained network, in memory (bytes)
         self._eng, self._eng_sig = None, None
         self.next_stream = 1
         self.history = []
@@ -90,7 +92,7 @@ class SelfPlayTrainLoop:
         elif self.forward_factory is not None:
             eng.set_forward(self.forward_factory(self.net))
         else:
-            eng.set_model_module(self.traced)       # hot swap through memory: no file, no polling
+            eng.set_model_bytes(self.traced)        # hot swap through memory: no file, no polling
         eng.begin(games)
         done = 0
         while done < games:
@@ -120,10 +122,18 @@ class SelfPlayTrainLoop:
         self.window.add(iteration, states, dists, outcomes)
         lr = T.learning_rate_for(self.tcfg, iteration)
         best, hist = T.train_network(self.net, lr, self.window.training_tensors(iteration), self.tcfg)
-        self.model_path = os.path.join(self.root, "data", "models", self.cfg.run_name,
-                                       f"traced_{self.cfg.run_name}_iteration_{iteration}.pt")
-        T.export_best(self.net, best, self.cfg.game, self.model_path)
-        self.traced = torch.jit.load(self.model_path, map_location="cpu") if self.forward_factory is None else True
+        # the best-validation weights traced into a TorchScript archive IN MEMORY (what othello_controller.py:237-239 writes to
+        # traced_<run>_iteration_<i>.pt); the file itself only exists with write_files=True, for the reference tooling
+        self.traced = T.export_best_bytes(self.net, best, self.cfg.game) if self.forward_factory is None else True
+        if self.cfg.write_files:
+            self.model_path = os.path.join(self.root, "data", "models", self.cfg.run_name,
+                                           f"traced_{self.cfg.run_name}_iteration_{iteration}.pt")
+            if self.traced is True:
+                T.export_best(self.net, best, self.cfg.game, self.model_path)
+            else:
+                with open(self.model_path + ".tmp", "wb") as f:
+                    f.write(self.traced)
+                os.replace(self.model_path + ".tmp", self.model_path)
         rec = dict(iteration=iteration, samples=int(states.shape[0]), games=stats["games"], lr=lr,
                    best_epoch=hist["best_epoch"], best_val=hist["best_val"], model=self.model_path)
         self.history.append(rec)

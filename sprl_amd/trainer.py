@@ -15,7 +15,7 @@ from typing import List, Optional
 
 import torch
 
-from .network import trace_to_file
+from .network import trace_to_bytes, trace_to_file
 
 EPS = 1e-8  # othello_controller.py:150
 
@@ -82,18 +82,18 @@ def learning_rate_for(cfg: TrainerConfig, iteration: int) -> float:
 
 
 def _evaluate(net, tensors, batches):
-    """Mean over validation batches of the two weighted losses; returns (policy sum, value sum, batch count)."""
+    """Sums over validation batches of the two weighted losses as one float64 DEVICE tensor [policy sum, value sum, batch
+    count]: nothing is read back per batch, the caller synchronises once per epoch."""
     s, d, o, t = tensors
-    pol = val = 0.0
-    n = 0
+    acc = torch.zeros(3, device=s.device, dtype=torch.float64)
     with torch.no_grad():
         for b in batches:
             lo, va = net(s[b])
             p, v = weighted_losses(lo, va, d[b], o[b], t[b])
-            pol += p.item()
-            val += v.item()
-            n += 1
-    return pol, val, n
+            acc[0] += p.double()
+            acc[1] += v.double()
+            acc[2] += 1.0
+    return acc
 
 
 def _dist():
@@ -123,6 +123,9 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
         perm = torch.randperm(n, device=device, generator=generator)
         n_train = int((1.0 - cfg.val_fraction) * n)                              # :135-138
         train_idx, val_idx = perm[:n_train], perm[n_train:]
+        if train_idx.numel() == 0:
+            raise ValueError(f"train_network: this rank's shard has {n} samples, none left for training after the "
+                             f"{cfg.val_fraction:.0%} validation split")
         steps = (train_idx.numel() + cfg.batch_size - 1) // cfg.batch_size
         if dist is not None:                                                     # same number of all-reduces on every rank
             st = torch.tensor([steps], device=device)
@@ -147,7 +150,9 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                     order = order.repeat((steps * cfg.batch_size + order.numel() - 1) // order.numel())[:steps * cfg.batch_size]
                 train_batches = [order[k:k + cfg.batch_size] for k in range(0, order.numel(), cfg.batch_size)]
                 val_batches = [val_idx[k:k + cfg.batch_size] for k in range(0, val_idx.numel(), cfg.batch_size)]
-            tp = tv = 0.0
+            # losses are accumulated on the device in float64 (the same sums as the reference's Python floats, :181-182) and read
+            # back ONCE per epoch: the reference's `.item()` per batch would drain the GPU queue after every optimiser step
+            tacc = torch.zeros(2, device=device, dtype=torch.float64)
             nb = 0
             for b in train_batches:
                 lo, va = model(s[b])
@@ -155,8 +160,8 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                 opt.zero_grad(set_to_none=True)
                 (pl + vl).backward()
                 opt.step()
-                tp += pl.item()
-                tv += vl.item()
+                tacc[0] += pl.detach().double()
+                tacc[1] += vl.detach().double()
                 nb += 1
             model.eval()
             if dist is not None:                                                 # BatchNorm running statistics: average the ranks'
@@ -164,12 +169,16 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                     if buf.is_floating_point():
                         dist.all_reduce(buf)
                         buf /= dist.get_world_size()
-            vp, vv, vn = _evaluate(net, tensors, val_batches) if len(val_batches) else (tp, tv, nb)
-            if dist is not None:                                                 # one decision for all ranks
-                sums = torch.tensor([vp, vv, float(vn)], device=device, dtype=torch.float64)
+            # [val policy, val value, val batches, train policy, train value, train batches]; a rank without validation batches
+            # contributes zeros, and the training sums stand in only when NO rank has any (a tiny window)
+            sums = torch.cat([_evaluate(net, tensors, val_batches), tacc, torch.tensor([float(nb)], device=device, dtype=torch.float64)])
+            tp, tv = sums[3:5].tolist()                                          # this rank's own training sums (the epoch's
+            if dist is not None:                                                 # host synchronisation); one decision for all ranks
                 dist.all_reduce(sums)
-                vp, vv, vn = float(sums[0]), float(sums[1]), int(round(float(sums[2])))
-            vp, vv = vp / max(1, vn), vv / max(1, vn)
+            vp, vv, vn, gtp, gtv, gnb = sums.tolist()
+            if vn < 0.5:
+                vp, vv, vn = gtp, gtv, gnb
+            vp, vv = vp / max(1.0, vn), vv / max(1.0, vn)
             val_loss = vp + vv
             history.append(dict(epoch=e, train_policy=tp / nb, train_value=tv / nb, val_policy=vp, val_value=vv))
             if val_loss < best_val:                                              # :210-219
@@ -189,3 +198,10 @@ def export_best(net, best_state, game, path):
     snap = copy.deepcopy(net).cpu()
     snap.load_state_dict(best_state)
     return trace_to_file(snap.eval(), path, game)
+
+
+def export_best_bytes(net, best_state, game) -> bytes:
+    """The same traced archive in memory, for the in-process hot swap (no file)."""
+    snap = copy.deepcopy(net).cpu()
+    snap.load_state_dict(best_state)
+    return trace_to_bytes(snap.eval(), game)

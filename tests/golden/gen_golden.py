@@ -332,6 +332,30 @@ def g_go9():
     save("g_go9.npz", **out)
 
 
+def g_go19():
+    """Go at 19x19 (BASELINE config 5): the reference compiled with GO_BOARD_WIDTH = 19, GO_KOMI = 7.5 and its two index
+    types widened to int16_t (games/GoNode.hpp:16,20,36-37; oracle/Makefile: ref_go19, four changed lines) - rules play-outs
+    (captures, superko, the 2N depth cap, Tromp-Taylor + komi), a 200-traversal search trace at the worker's 16/8 batching
+    and whole games."""
+    L = pyref.lib(variant="go19")
+    assert L.ref_go_board_width() == 19 and abs(L.ref_go_komi() - 7.5) < 1e-6
+    out = {}
+    for i, seed in enumerate((11, 22, 33, 44)):
+        r = pyref.playout("go19", seed, 1, 800)
+        for k, v in r.items():
+            out[f"playout_{i}_{k}"] = v
+        out[f"playout_{i}_seed"] = np.array([seed], np.int64)
+    st, tr, ch = pyref.search_trace("go19", 0, 3, 200, 16, 8, 0.25, 0.2, SEED, 1)
+    out["trace_stats"], out["trace_trav"], out["trace_chosen"] = st, tr, ch
+    r = pyref.selfplay("go19", 0, 1, 32, 16, 8, 0.25, 0.2, SEED, 1, True)
+    for k in ("boards", "players", "sizes", "dists", "outcomes", "offsets"):
+        out["games_" + k] = r[k]
+    r = pyref.selfplay("go19", 0, 1, 40, 4, 2, 0.25, 0.2, SEED, 7, True, use_sym=0, add_noise=0)
+    for k in ("boards", "players", "sizes", "dists", "outcomes", "offsets"):
+        out["games_nosym_" + k] = r[k]
+    save("g_go19.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trainer":
         g_trainer()
@@ -342,6 +366,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "go9":          # only the 9x9 fixtures (needs `make -C oracle ref_go9`)
         assert pyref.available(variant="go9"), "run `make -C oracle ref_go9` first"
         g_go9()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "go19":        # only the 19x19 fixtures (needs `make -C oracle ref_go19`)
+        assert pyref.available(variant="go19"), "run `make -C oracle ref_go19` first"
+        g_go19()
         sys.exit(0)
     assert pyref.available() and pyref.available(True), "run `make -C oracle ref ref_torch` first"
     g6_rng()
@@ -355,3 +383,5 @@ if __name__ == "__main__":
     g10_matches()
     if pyref.available(variant="go9"):
         g_go9()
+    if pyref.available(variant="go19"):
+        g_go19()

@@ -55,20 +55,18 @@ def test_node_recycling_keeps_arena_small(emu):
         assert st["nodes_recycled"] > 0 and st["compactions"] == 0
 
 
-def test_child_indices_beyond_16_bits(emu, monkeypatch):
+def test_child_indices_beyond_16_bits(emu):
     """a move's tree may exceed 65535 nodes (the reference worker's iteration-0 budget is 131072
     traversals/move at batch 1, OTHWorker.cpp:17-20).  Arenas above 65535 nodes switch to 24-bit child indices (u16 row +
     u8 row).  The allocator is started at node 65400 (test hook), so a short game's ids run across the 16-bit boundary -
     with bump allocation, with recycling and through a compaction."""
-    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65400")
-    rec, st = parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=40, node_cap=70000, no_recycle=1, seed=3)
+    rec, st = parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=40, node_cap=70000, no_recycle=1, seed=3,
+                                alloc_base=65400)
     assert st["max_nodes_in_arena"] > 65535 + 500 and st["compactions"] == 0
-    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65520")
-    rec, st = parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=40, node_cap=70000, seed=3)
+    rec, st = parity.check_case(emu, "othello", 1, concurrent_games=1, num_traversals=40, node_cap=70000, seed=3, alloc_base=65520)
     assert st["max_nodes_in_arena"] > 65535 and st["nodes_recycled"] > 0
-    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65400")
     rec, st = parity.check_case(emu, "go", 1, concurrent_games=1, num_traversals=60, node_cap=65400 + 700, spare_arenas=2,
-                                no_recycle=1, seed=5)
+                                no_recycle=1, seed=5, alloc_base=65400)
     assert st["compactions"] > 0
 
 

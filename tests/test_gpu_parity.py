@@ -99,13 +99,18 @@ def test_node_recycling_small_arenas(lib):
     assert st["compactions"] == 0 and st["max_nodes_in_arena"] < 4224 and st["nodes_recycled"] > 0.9 * st["nodes_created"]
 
 
-def test_child_indices_beyond_16_bits(lib, monkeypatch):
+def test_child_indices_beyond_16_bits(lib):
     """Arenas above 65535 nodes: 24-bit child indices (the reference's iteration-0 budget of 131072 traversals per
     move does not fit 16-bit indices).  The allocator is started next to the boundary (test hook), then a real large budget."""
-    monkeypatch.setenv("SPRL_TEST_ALLOC_BASE", "65400")
-    rec, st = parity.check_case(lib, "othello", 2, concurrent_games=2, num_traversals=40, node_cap=70000, no_recycle=1, seed=3)
+    rec, st = parity.check_case(lib, "othello", 2, concurrent_games=2, num_traversals=40, node_cap=70000, no_recycle=1, seed=3,
+                                alloc_base=65400)
     assert st["max_nodes_in_arena"] > 65535 + 500 and st["compactions"] == 0
-    monkeypatch.delenv("SPRL_TEST_ALLOC_BASE")
+    # the reference's real iteration-0 constants (OTHWorker.cpp:17-20: 3 games x 131072 traversals, batch 1 / queue 1), eight
+    # tasks covered by one engine: the default arena (2 x traversals + 5120 nodes = 0.26 GiB per game) must fit comfortably
+    cfg = E.default_config("othello", lib, concurrent_games=24, num_traversals=131072, max_batch=1, max_queue=1)
+    eng = E.Engine(cfg, lib)
+    assert eng.stats()["hbm_bytes"] < 24 * 0.3 * 2 ** 30 + 2 ** 30
+    eng.close()
     # a whole game at 65536 traversals/move, batch 1 / queue 1 (the shape of the reference's iteration 0), bit-exact vs the oracle
     rec, st = parity.check_case(lib, "othello", 1, concurrent_games=1, num_traversals=65536, max_batch=1, max_queue=1, seed=9)
     assert st["max_nodes_in_arena"] > 65535 and st["compactions"] == 0
@@ -330,7 +335,8 @@ def test_in_process_selfplay_training_loop(lib, tmp_path):
     own = (ora["boards"] == ora["players"][:, None]).reshape(-1, 6, 7)
     assert (s0[:, 0].cpu().numpy() == own).all() and (s0[:, 2, 0, 0].cpu().numpy() == (ora["players"] == 0)).all()
     # the model went back to the engine through memory (sprl_engine_set_model_buffer) and was used: evaluations happened
-    assert hist[1]["samples"] > 0 and loop.traced is not None
+    assert hist[1]["samples"] > 0 and isinstance(loop.traced, bytes)
+    assert not list(tmp_path.rglob("*.pt")) and not list(tmp_path.rglob("*.npy"))     # nothing went through the file system
 
 
 # ---- match play (Evaluate.cpp) on the device ----

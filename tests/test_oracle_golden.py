@@ -288,6 +288,63 @@ def test_go9_live_reference():
         assert (bits(o["masks"]) == bits(r["masks"])).all()
 
 
+# ---- Go at 19x19 (BASELINE config 5): fixtures from the reference compiled with FOUR lines changed - GO_BOARD_WIDTH = 19,
+# GO_KOMI = 7.5 and Coord / LibertyCount int8_t -> int16_t (games/GoNode.hpp:16,20,36-37; oracle/Makefile: ref_go19;
+# tests/golden/gen_golden.py: g_go19) -----------------------------------------------------------------------------------
+def test_go19_playouts_pinned(golden):
+    g = golden("g_go19.npz")
+    for i in range(4):
+        r = po.playout(po.GAME_GO19, int(g[f"playout_{i}_seed"][0]), 1, 800)
+        for k in ("boards", "players", "actions", "terminal"):
+            assert r[k].shape == g[f"playout_{i}_{k}"].shape and (r[k] == g[f"playout_{i}_{k}"]).all(), (i, k)
+        assert (bits(r["masks"]) == bits(g[f"playout_{i}_masks"])).all()
+        assert (r["rewards"] == g[f"playout_{i}_rewards"]).all()          # Tromp-Taylor area + komi 7.5
+        assert r["terminal"][-1] == 1 and r["boards"].shape[1] == 8 * 361 and r["masks"].shape[1] == 362
+        assert len(r["actions"]) > 300                                    # long enough for captures, ko and superko to occur
+
+
+def test_go19_search_trace_pinned(golden):
+    g = golden("g_go19.npz")
+    cfg = po.make_config(po.GAME_GO19, 200, max_batch=16, max_queue=8, dir_alpha=0.2)
+    st, tr, ch = po.search_trace(cfg, 3, SEED, 1)
+    assert (tr == g["trace_trav"]).all() and (ch == g["trace_chosen"]).all()
+    assert (bits(st) == bits(g["trace_stats"])).all()
+
+
+@pytest.mark.parametrize("name,kw,ngames,stream", [
+    ("games", dict(num_traversals=32, max_batch=16, max_queue=8, dir_alpha=0.2), 1, 1),
+    ("games_nosym", dict(num_traversals=40, max_batch=4, max_queue=2, dir_alpha=0.2, use_sym=0, add_noise=0), 1, 7)])
+def test_go19_whole_games_pinned(golden, name, kw, ngames, stream):
+    g = golden("g_go19.npz")
+    r = po.selfplay(po.make_config(po.GAME_GO19, **kw), ngames, SEED, stream, True)
+    assert (r["offsets"] == g[name + "_offsets"]).all()
+    for k in ("boards", "players", "sizes", "outcomes"):
+        assert (r[k] == g[f"{name}_{k}"]).all(), k
+    assert (bits(r["dists"]) == bits(g[name + "_dists"])).all()
+
+
+@pytest.mark.skipif(not pyref.available(variant="go19"), reason="prebuilt 19x19 reference library not present")
+def test_go19_live_reference():
+    """Fresh seeds: oracle at width 19 == the reference compiled at width 19 - whole games at the worker's 16/8 batching and a
+    search at the worker's 1600-traversal budget (GoWorker.cpp:23)."""
+    L = pyref.lib(variant="go19")
+    assert L.ref_go_board_width() == 19 and L.ref_go_komi() == 7.5
+    for trav, ngames, seed in ((64, 1, 99101), (24, 2, 99102)):
+        r = pyref.selfplay("go19", 0, ngames, trav, 16, 8, 0.25, 0.2, seed, 2, True)
+        o = po.selfplay(po.make_config(po.GAME_GO19, trav, max_batch=16, max_queue=8, dir_alpha=0.2), ngames, seed, 2, True)
+        assert (o["offsets"] == r["offsets"]).all()
+        for k in ("boards", "players", "sizes", "outcomes"):
+            assert (o[k] == r[k]).all(), k
+        assert (bits(o["dists"]) == bits(r["dists"])).all()
+    st, tr, ch = pyref.search_trace("go19", 0, 2, 1600, 16, 8, 0.25, 0.2, 99103, 4)
+    st2, tr2, ch2 = po.search_trace(po.make_config(po.GAME_GO19, 1600, max_batch=16, max_queue=8, dir_alpha=0.2), 2, 99103, 4)
+    assert (tr == tr2).all() and (ch == ch2).all() and (bits(st) == bits(st2)).all()
+    for seed in (5, 6, 7):
+        r, o = pyref.playout("go19", seed, 3, 800), po.playout(po.GAME_GO19, seed, 3, 800)
+        assert all((o[k] == r[k]).all() for k in ("boards", "players", "actions", "terminal", "rewards"))
+        assert (bits(o["masks"]) == bits(r["masks"])).all()
+
+
 def _match_cfg(game, kind, trav, mb, mq, sym, parent_q):
     # tree options of Evaluate.cpp:94-112 (eps 0.25, alpha 0.1, noise on, default u-weight 1.0)
     return po.make_config(GAMES[game], trav, max_batch=mb, max_queue=mq, dir_eps=0.25, dir_alpha=0.1, u_weight=1.0,

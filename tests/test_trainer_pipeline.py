@@ -90,6 +90,26 @@ def test_in_process_loop_hot_swaps_the_model(tmp_path):
     m = torch.jit.load(str(tmp_path / "data" / "models" / "loop" / "traced_loop_iteration_1.pt"))
     lo, va = m(torch.zeros(2, 3, 6, 7))
     assert lo.shape == (2, 7) and va.shape == (2, 1)
+    # without write_files nothing touches the file system (no .pt rendez-vous, no .npy round trip)
+    quiet = tmp_path / "quiet"
+    quiet.mkdir()
+    cfg2 = LoopConfig(game="connect_four", num_iters=2, init_games=2, init_traversals=8, init_max_batch=8, init_max_queue=4,
+                      games=2, traversals=8, num_blocks=1, num_channels=8, root=str(quiet), run_name="q")
+    loop2 = SelfPlayTrainLoop(cfg2, tcfg, lib=emu, forward_factory=forward_factory, train_device="cpu", log=lambda *_: None)
+    assert len(loop2.run()) == 2 and not list(quiet.rglob("*"))
+
+
+def test_trace_to_bytes_is_the_file_archive(tmp_path):
+    """The in-memory archive handed to sprl_engine_set_model_buffer loads to the same module as the reference-style file."""
+    import io
+    from sprl_amd.network import make_network, trace_to_bytes, trace_to_file
+    net = make_network("connect_four", 1, 8, seed=3)
+    raw = trace_to_bytes(net, "connect_four")
+    a = torch.jit.load(io.BytesIO(raw))
+    b = torch.jit.load(trace_to_file(net, str(tmp_path / "t.pt"), "connect_four"))
+    x = torch.rand(3, 3, 6, 7)
+    for u, v in zip(a(x), b(x)):
+        assert torch.equal(u, v)
 
 
 @pytest.mark.parametrize("game", ["c4", "othello", "go", "go9"])
