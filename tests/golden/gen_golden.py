@@ -196,8 +196,9 @@ def g9b_baseline_network():
     import netfill
     seed = 20261004
     x = netfill.othello_like_inputs(64, seed + 1)
-    out = dict(seed=np.array([seed], np.int64), input=x, gains=np.array([1.0, 2.0]))
-    for gi, gain in enumerate((1.0, 2.0)):       # default-init scale ("random-init net"), and logits of trained-network size
+    out = dict(seed=np.array([seed], np.int64), input=x, gains=np.array([1.0, 2.0, 3.0]))
+    # default-init scale ("random-init net", |logits| <= 0.1), |logits| <= 3.3, and |logits| <= 16 (a sharply trained policy head)
+    for gi, gain in enumerate((1.0, 2.0, 3.0)):
         ref_net = netfill.fill_state_dict(BasicGridNetwork(8, 8, 65, 1, 2, 64), seed + gi, gain).eval()
         with torch.no_grad():
             logits, value = ref_net(torch.from_numpy(x))

@@ -207,8 +207,19 @@ def test_torchscript_cnn_through_libtorch(lib, traced_model):
 # Measured on MI355X (profiles/r02_cnn_error.txt): on the BASELINE-shape network the hand-written fp32 path (Winograd
 # F(4x4,3x3) trunk on fp32 MFMA) differs from the reference's fp32 outputs by 1.5e-8 (default-init scale, |logits| <= 0.1) and
 # 3.6e-6 (logits of size 3; the reference's own fp32 is 1.5e-6 from float64 there); on positions the engine recorded 7.6e-8.
-# Tolerance = SURVEY section 8(c)'s 1e-5, 2.8x the largest error seen.
+# Tolerance = SURVEY section 8(c)'s 1e-5, 2.8x the largest error seen - at those magnitudes.  An absolute bound cannot hold at
+# every scale in fp32 (the reference's OWN CPU fp32 forward is 1.1e-5 from float64 at |logits| = 16, g9b gain 3), so the
+# tolerance is stated as  max(CNN_ATOL, CNN_RTOL x the largest |logit| of the batch's network output): CNN_RTOL is relative to
+# the output scale, not to each element (a logit near zero that is the difference of large terms carries their error).
+# Measured on MI355X (round 3, gpurun_out/r03a_gpu_tests.log -> profiles/r03_cnn_error.txt): gain 3, |logits| <= 16: 4.2e-5 from
+# the reference's fp32 outputs = 2.6e-6 of the scale (gain 2: 1.1e-6 of the scale; the reference's own fp32: 0.7e-6).
+# CNN_RTOL = 5e-6 is 1.9x the largest relative error seen.
 CNN_ATOL = 1e-5
+CNN_RTOL = 5e-6
+
+
+def cnn_tol(reference_logits):
+    return max(CNN_ATOL, CNN_RTOL * float(np.abs(reference_logits).max()))
 
 
 def test_handwritten_cnn_against_reference_golden_baseline_shape(lib, golden, tmp_path):
@@ -236,9 +247,10 @@ def test_handwritten_cnn_against_reference_golden_baseline_shape(lib, golden, tm
         e_ref = max(np.abs(lo - g[f"logits{gi}"]).max(), np.abs(va - g[f"value{gi}"].reshape(-1)).max())
         e_f64 = max(np.abs(lo - g[f"logits_f64_{gi}"]).max(), np.abs(va - g[f"value_f64_{gi}"].reshape(-1)).max())
         cpu_f64 = max(np.abs(g[f"logits{gi}"] - g[f"logits_f64_{gi}"]).max(), np.abs(g[f"value{gi}"] - g[f"value_f64_{gi}"]).max())
-        report.append(f"gain {gain}: |logits| <= {np.abs(g[f'logits{gi}']).max():.2f}; hand-written vs reference fp32 {e_ref:.3e}, "
-                      f"vs float64 {e_f64:.3e}; reference fp32 vs float64 {cpu_f64:.3e}")
-        assert e_ref < CNN_ATOL, report[-1]
+        scale = float(np.abs(g[f"logits{gi}"]).max())
+        report.append(f"gain {gain}: |logits| <= {scale:.2f}; hand-written vs reference fp32 {e_ref:.3e} (= {e_ref / scale:.2e} of the "
+                      f"scale), vs float64 {e_f64:.3e}; reference fp32 vs float64 {cpu_f64:.3e}; tolerance {cnn_tol(g[f'logits{gi}']):.1e}")
+        assert e_ref < cnn_tol(g[f"logits{gi}"]), report[-1]
     print("\n".join(report))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", "cnn_error.txt"), "w").write("\n".join(report) + "\n")
@@ -471,9 +483,9 @@ def test_private_stream_go9_host_batch_path(lib, tmp_path):
 
 
 def test_go9_plugin_forward_matches_torchscript(lib, tmp_path):
-    """9x9 boards: library convolutions + the hand-written bias/BN/ReLU(/residual) epilogue and fused 1x1 heads (H*W = 81 is
-    not a multiple of 4: scalar epilogue form) and the hand-written NCHW stem (17 planes) against the plain TorchScript fp32
-    forward, 1e-5 absolute; also at 19x19."""
+    """9x9 and 19x19 boards, 64-channel trunk: the whole forward in hand-written kernels (plugin kind 2, asserted - a silent
+    fall-back to the library convolutions would not count): NCHW stem for 17 planes on the matrix cores, any-board
+    Winograd/MFMA trunk, 1x1 heads, FC tail; against the plain TorchScript fp32 forward of the same file."""
     import ctypes as C
     import torch
     from sprl_amd.network import make_network, trace_to_file
@@ -483,9 +495,11 @@ def test_go9_plugin_forward_matches_torchscript(lib, tmp_path):
     plug.sprl_torch_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     plug.sprl_torch_forward.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p,
                                                                                  C.c_char_p, C.c_int]
+    plug.sprl_torch_is_native.argtypes = [C.c_void_p]
     err = C.create_string_buffer(512)
     h = plug.sprl_torch_load(model.encode(), 0, err, 512)
     assert h, err.value
+    assert plug.sprl_torch_is_native(h) == 2
     ref = torch.jit.load(model, map_location="cuda").eval()
     for batch in (5, 1024):
         x = (torch.rand(batch, 17, 9, 9, device="cuda") > 0.6).float().contiguous()
@@ -500,6 +514,7 @@ def test_go9_plugin_forward_matches_torchscript(lib, tmp_path):
     model19 = trace_to_file(make_network("go19", 2, 64, seed=6), str(tmp_path / "traced_go19.pt"), "go19")
     h19 = plug.sprl_torch_load(model19.encode(), 0, err, 512)
     assert h19, err.value
+    assert plug.sprl_torch_is_native(h19) == 2
     ref19 = torch.jit.load(model19, map_location="cuda").eval()
     x = (torch.rand(37, 17, 19, 19, device="cuda") > 0.6).float().contiguous()
     lo = torch.zeros(37, 362, device="cuda")
@@ -513,8 +528,9 @@ def test_go9_plugin_forward_matches_torchscript(lib, tmp_path):
 
 
 def test_go9_with_traced_cnn_generic_path(lib, tmp_path):
-    """Boards wider than 8 have no hand-written trunk: the traced model runs through LibTorch (MIOpen convolutions or the
-    rewritten TorchScript graph).  Games must be complete and legal-looking, policies normalised."""
+    """A trunk that is not 64 channels wide (here 1 block x 32) has no hand-written Winograd kernel: the recognised architecture
+    runs as library convolutions + the hand-written fused epilogue (plugin kind 1).  Games must be complete and legal-looking,
+    policies normalised."""
     from sprl_amd.network import make_network, trace_to_file
     model = trace_to_file(make_network("go9", 1, 32, seed=2), str(tmp_path / "traced_go9.pt"), "go9")
     cfg, rec, st = parity.run_engine(lib, "go9", 6, model=model, concurrent_games=6, num_traversals=40)

@@ -216,10 +216,12 @@ def test_g9b_baseline_shape_network_contract(golden):
         assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
         with torch.no_grad():
             lo, va = net(torch.from_numpy(g["input"]))
-        np.testing.assert_allclose(lo.numpy(), g[f"logits{gi}"], atol=1e-5, rtol=0)
+        scale = float(np.abs(g[f"logits{gi}"]).max())               # 0.1, 3.3, 16
+        np.testing.assert_allclose(lo.numpy(), g[f"logits{gi}"], atol=max(1e-5, 1e-6 * scale), rtol=0)
         np.testing.assert_allclose(va.numpy(), g[f"value{gi}"], atol=1e-5, rtol=0)
-        # how far fp32 itself is from the exact (float64) forward: the yardstick for the GPU tolerance
-        assert np.abs(g[f"logits{gi}"] - g[f"logits_f64_{gi}"]).max() < 5e-6
+        # how far fp32 itself is from the exact (float64) forward: the yardstick for the GPU tolerance - the reference's own
+        # CPU fp32 forward is 1.1e-5 off at |logits| = 16, i.e. an ABSOLUTE 1e-5 cannot hold at trained-network scale
+        assert np.abs(g[f"logits{gi}"] - g[f"logits_f64_{gi}"]).max() < max(5e-6, 1e-6 * scale)
 
 
 @pytest.mark.skipif(not pyref.available(), reason="prebuilt reference library not present")
