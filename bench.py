@@ -249,6 +249,18 @@ def main():
         t_load = time.perf_counter() - t_load
         gather_s = [0.0]
         shard_bytes = [0]
+        last_shards = []                            # rank 0: the packed shards of the last emit, host bytes
+
+        def verify_last_shards():
+            """Outside the timed region: decode the last step's shards and check them (every rank's games present, pdfs are
+            distributions) - the proof that what was gathered is usable, without numpy bit-unpacking inside the bracket."""
+            from sprl_amd.distributed import unpack_records
+            if not last_shards:
+                return None
+            un = [unpack_records(t.numpy()) for t in last_shards]
+            for sh in un:
+                assert sh["ply_offset"][-1] == sh["total_plies"] and abs(float(sh["pdfs"].sum()) - sh["total_plies"]) < 1e-2 * sh["total_plies"]
+            return {"shards": len(un), "games": [int(sh["num_games"]) for sh in un], "plies": [int(sh["total_plies"]) for sh in un]}
 
         def emit_records(en):
             """The finished games' compact records, packed ON THE DEVICE from the engine's record buffers (records_kernel.h).
@@ -261,10 +273,16 @@ def main():
             shard_bytes[0] = nbytes
             if dist is None:
                 host = shard.cpu()
+                last_shards[:] = [host]
                 return int(host[:16].view(torch.int64)[1])            # head[1] = plies of the shard
-            shards = gather_packed(shard if comm_device.type == "cuda" else shard.cpu(), nbytes, dist)
+            # rank 0 receives the packed shards and copies the bytes to the host (as at N = 1); they are DECODED after the timed
+            # region (verify_last_shards), not inside it
+            shards = gather_packed(shard if comm_device.type == "cuda" else shard.cpu(), nbytes, dist, unpack=False)
             torch.cuda.synchronize()
-            return sum(sh["total_plies"] for sh in shards) if shards is not None else plies
+            if shards is None:
+                return plies
+            last_shards[:] = shards
+            return sum(int(sh[:16].view(torch.int64)[1]) for sh in shards)
 
         def play(en, n_games):
             en.begin(n_games)
@@ -324,12 +342,13 @@ def main():
         tree_busy, tree_sum = E.profile_busy(lib, 0)
         conv_busy, conv_sum = E.profile_busy(lib, 1) if model_path else (None, None)
         d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
+        verified = verify_last_shards()
         info = engines[0].evaluator_info() if model_path else args.model
         for en in engines:
             en.close()
         return dict(pops=pops, steps=steps, elapsed=elapsed, d=d, st1=st1, tree_busy=tree_busy, tree_sum=tree_sum,
                     conv_busy=conv_busy, conv_sum=conv_sum, t_load=t_load, gather_s=gather_s[0], shard_bytes=shard_bytes[0],
-                    evaluator=info)
+                    evaluator=info, verified=verified)
 
     def rooflines(M):
         """(roofline of the trunk convolution or None, roofline of the tree kernel or None) of one measure() result.
@@ -400,6 +419,15 @@ def main():
     if pops > 1 and not args.no_profile and not args.no_alone_pass and args.game == "othello":     # (a Go step is minutes long)
         M1 = measure(1, 1, 0)
 
+    # what the collective backend really saw: world size, backend name and every rank's device, gathered from the ranks themselves
+    me = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "name": torch.cuda.get_device_name(local_rank),
+          "pid": os.getpid()}
+    if dist is not None:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks_info}
+    else:
+        dist_info = {"world_size": 1, "backend": None, "ranks": [me]}
     if rank == 0:
         total_games = games * args.steps * world
         bpt, shape = algorithmic_bytes_per_traversal(d, A=G["A"], mask_bytes=G["mask_bytes"], board_bytes=G["board_bytes"],
@@ -425,6 +453,7 @@ def main():
                        "evaluator": (f"traced CNN {args.blocks}x{args.channels} fp32, " + M["evaluator"] if model_path else args.model),
                        "parallelism": (f"game-sharded x{world}, records packed on the device, one gather per step over {backend_name}"
                                        if world > 1 else "1 GPU")},
+            "distributed": dict(dist_info, gathered_last_step=M["verified"]),
             "expansions_per_sec": d["expansions"] * world / elapsed,
             "traversals_per_sec": d["traversals"] * world / elapsed,
             "nn_evals_per_sec": d["nn_evals"] * world / elapsed,

@@ -83,10 +83,12 @@ def unpack_records(buf):
                 pdfs=pdfs, nbytes=off["total"])
 
 
-def gather_packed(shard, nbytes, dist, dst=0):
+def gather_packed(shard, nbytes, dist, dst=0, unpack=True):
     """Gather every rank's packed shard (a 1-D uint8 torch tensor on the backend's device: CUDA for "nccl" = RCCL,
     CPU for "gloo") to rank `dst`: an all_gather of the byte counts, then one gather of equal-sized padded shards.
-    Returns the list of unpacked shards on `dst` (rank order = game-shard order), None elsewhere."""
+    Returns on `dst` the list of unpacked shards (rank order = game-shard order), or with unpack=False the raw packed shards
+    as HOST uint8 tensors (one device-to-host copy each, no decoding: what a producer that only forwards or writes the bytes
+    needs; decode later with unpack_records); None on the other ranks."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     size = torch.tensor([int(nbytes)], dtype=torch.int64, device=shard.device)
@@ -104,7 +106,8 @@ def gather_packed(shard, nbytes, dist, dst=0):
     dist.gather(shard, outs, dst=dst)
     if rank != dst:
         return None
-    return [unpack_records(t[:s].cpu().numpy()) for t, s in zip(outs, sizes)]
+    raw = [t[:s].cpu() for t, s in zip(outs, sizes)]
+    return [unpack_records(t.numpy()) for t in raw] if unpack else raw
 
 
 def gather_records(rec, dist, device="cpu", dst=0):

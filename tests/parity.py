@@ -104,3 +104,79 @@ def check_match(lib, game, agents, num_games, seed=11, forwards=(None, None), or
     assert (actions == oa).all()
     assert (winners == ow).all()
     return winners, actions, nplies
+
+
+# ---- distributional parity of the CNN path (SURVEY section 7 hard-part iii) -----------------------------------------------
+def game_statistics(ply_offset, pdfs, outcome_player0, evals=None):
+    """Per-game (plies, outcome for Player ZERO, mean entropy of the recorded root-visit pdfs)."""
+    lengths = np.diff(ply_offset)
+    p = np.asarray(pdfs, np.float64)
+    h = -(p * np.log(np.where(p > 0, p, 1.0))).sum(1)
+    ent = np.array([h[ply_offset[g]:ply_offset[g + 1]].mean() for g in range(len(lengths))])
+    return dict(plies=lengths.astype(np.float64), outcome=np.asarray(outcome_player0, np.float64), entropy=ent,
+                evals=None if evals is None else np.asarray(evals, np.float64))
+
+
+def reference_cnn_games(args):
+    """Pool worker (spawn context, never touches the GPU): `games` Othello games of the REFERENCE's selfPlay + GridNetwork on
+    LibTorch-CPU (oracle/_ref/libsprl_ref_torch.so, networks/GridNetwork.hpp:62-145, selfplay/SelfPlay.hpp:51-192) with the traced
+    model; returns per game (plies, outcome of Player ZERO, network evaluations, mean pdf entropy)."""
+    import os
+    model, games, trav, seed, stream = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["MKL_NUM_THREADS"] = "1"
+    import torch
+    torch.set_num_threads(1)
+    from oracle import pyref
+    out = []
+    for g in range(games):
+        r = pyref.selfplay("othello", 0, 1, trav, 8, 4, 0.25, 0.3, seed, stream + g, True, model_path=model)
+        n = len(r["players"]) // 8
+        off = np.array([0, n])
+        first_mover = int(r["players"][0])                   # outcomes are rewards[mover] (SelfPlay.hpp:154-163)
+        z0 = float(r["outcomes"][0]) * (1.0 if first_mover == 0 else -1.0)
+        st = game_statistics(off, r["dists"][::8], [z0])
+        out.append((float(n), z0, float(r["evals"]), float(st["entropy"][0])))
+    return out
+
+
+# ---- f-2: the reference controller's training call, replayed (tests/golden/gen_golden.py: g_trainer) ----------------------------
+def replay_trainer_fixture(g, device, atol):
+    """Feeds the batches the REFERENCE's train_network drew (scripts/othello_controller.py:128-241) through sprl_amd.trainer on
+    `device`; checks best epoch, number of epochs, and the outputs of the best / live network on the probe batch.
+    Returns the largest absolute deviation from the reference's outputs."""
+    import os
+    import sys
+    import torch
+    from sprl_amd import trainer as T
+    from sprl_amd.network import GridResNet
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import netfill
+    seed, n = int(g["seed"][0]), int(g["n"][0])
+    states = torch.from_numpy(netfill.othello_like_inputs(n, seed)).to(device)
+    tensors = (states, torch.from_numpy(g["dists"]).to(device), torch.from_numpy(g["outcomes"]).to(device),
+               torch.from_numpy(g["stamps"]).to(device))
+    ntr, nva = (int(v) for v in g["batches_per_epoch"])
+    batches = [torch.from_numpy(g[f"batch{i}"].astype(np.int64)).to(device) for i in range(int(g["epochs"][0]) * (ntr + nva))]
+
+    def plan(epoch):
+        k = epoch * (ntr + nva)
+        return batches[k:k + ntr], batches[k + ntr:k + ntr + nva]
+
+    net = netfill.fill_state_dict(GridResNet(8, 8, 65, 1, 1, 8), seed).to(device)
+    cfg = T.TrainerConfig(batch_size=int(g["batch_size"][0]), max_groups=int(g["max_groups"][0]),
+                          epochs_per_group=int(g["epochs_per_group"][0]))
+    best, hist = T.train_network(net, float(g["lr"][0]), tensors, cfg, index_plan=plan)
+    assert hist["best_epoch"] == int(g["best_epoch"][0])
+    assert len(hist["epochs"]) == int(g["epochs"][0])             # the "best epoch is recent" continuation rule (:231-233)
+    with torch.no_grad():
+        flo, fva = net.eval()(states[:16])
+        snap = GridResNet(8, 8, 65, 1, 1, 8).to(device)
+        snap.load_state_dict(best)
+        blo, bva = snap.eval()(states[:16])
+    dev = 0.0
+    for ours, key in ((flo, "final_logits"), (fva, "final_value"), (blo, "best_logits"), (bva, "best_value")):
+        dev = max(dev, float(np.abs(ours.cpu().numpy() - g[key]).max()))
+        np.testing.assert_allclose(ours.cpu().numpy(), g[key], atol=atol, rtol=0)
+    np.testing.assert_allclose(g["traced_logits"], g["best_logits"], atol=1e-6, rtol=0)
+    return dev

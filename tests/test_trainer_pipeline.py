@@ -134,37 +134,10 @@ def test_trainer_against_reference_controller_fixture(golden):
     """f-2: tests/golden/g_trainer.npz was produced by the REFERENCE's train_network
     (scripts/othello_controller.py:128-241) on a synthetic window, recording the batches it drew.  Replayed on the same
     batches from the same initial weights, our trainer must select the same best epoch, stop after the same number of epochs
-    and end with the same weights: the saved best model and the live network agree on a probe batch to 1e-5."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-    import netfill
-    g = golden("g_trainer.npz")
-    seed, n = int(g["seed"][0]), int(g["n"][0])
-    states = torch.from_numpy(netfill.othello_like_inputs(n, seed))
-    tensors = (states, torch.from_numpy(g["dists"]), torch.from_numpy(g["outcomes"]), torch.from_numpy(g["stamps"]))
-    ntr, nva = (int(v) for v in g["batches_per_epoch"])
-    batches = [torch.from_numpy(g[f"batch{i}"].astype(np.int64)) for i in range(int(g["epochs"][0]) * (ntr + nva))]
-
-    def plan(epoch):
-        k = epoch * (ntr + nva)
-        return batches[k:k + ntr], batches[k + ntr:k + ntr + nva]
-
-    net = netfill.fill_state_dict(GridResNet(8, 8, 65, 1, 1, 8), seed)
-    cfg = T.TrainerConfig(batch_size=int(g["batch_size"][0]), max_groups=int(g["max_groups"][0]),
-                          epochs_per_group=int(g["epochs_per_group"][0]))
-    best, hist = T.train_network(net, float(g["lr"][0]), tensors, cfg, index_plan=plan)
-    assert hist["best_epoch"] == int(g["best_epoch"][0])
-    assert len(hist["epochs"]) == int(g["epochs"][0])             # the "best epoch is recent" continuation rule (:231-233)
-    with torch.no_grad():
-        flo, fva = net.eval()(states[:16])
-        snap = GridResNet(8, 8, 65, 1, 1, 8)
-        snap.load_state_dict(best)
-        blo, bva = snap.eval()(states[:16])
-    np.testing.assert_allclose(flo.numpy(), g["final_logits"], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(fva.numpy(), g["final_value"], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(blo.numpy(), g["best_logits"], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(bva.numpy(), g["best_value"], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(g["traced_logits"], g["best_logits"], atol=1e-6, rtol=0)
+    and end with the same weights: the saved best model and the live network agree on a probe batch to 1e-5.
+    (The same replay runs on the MI355X under -m gpu: tests/test_gpu_parity.py::test_trainer_fixture_on_the_gpu.)"""
+    import parity
+    parity.replay_trainer_fixture(golden("g_trainer.npz"), "cpu", atol=1e-5)
 
 
 DDP_SCRIPT = r"""

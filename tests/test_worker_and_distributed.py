@@ -108,7 +108,7 @@ import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import numpy as np, torch, torch.distributed as dist
 from sprl_amd import engine as E
-from sprl_amd.distributed import gather_records
+from sprl_amd.distributed import gather_packed, gather_records, pack_records, unpack_records
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 lib = E.load_library({emu!r})
@@ -117,6 +117,17 @@ cfg = E.default_config({game!r}, lib, concurrent_games=2, num_traversals={trav},
 eng = E.Engine(cfg, lib); eng.set_model("random")
 rec = eng.run(games)
 shards = gather_records(rec, dist)
+# the deferred-decoding form bench.py uses inside its timed bracket: raw host bytes now, unpack_records later
+payload = pack_records(rec)
+raw = gather_packed(torch.from_numpy(payload), payload.size, dist, unpack=False)
+if rank == 0:
+    assert len(raw) == world and all(r.dtype == torch.uint8 and r.device.type == "cpu" for r in raw)
+    for r, sh in zip(raw, shards):
+        late = unpack_records(r.numpy())
+        assert int(r[:16].view(torch.int64)[1]) == sh["total_plies"] == late["total_plies"]
+        assert (late["pdfs"].view(np.uint32) == sh["pdfs"].view(np.uint32)).all() and (late["boards"] == sh["boards"]).all()
+else:
+    assert raw is None
 if rank == 0:
     np.savez({out!r}, **{{f"r{{i}}_{{k}}": v for i, sh in enumerate(shards) for k, v in sh.items() if isinstance(v, np.ndarray)}})
 dist.barrier(); dist.destroy_process_group()
