@@ -299,6 +299,97 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
 }
 }  // namespace
 
+// The same tail for ANY board (Go 9x9 / 19x19), trunk output in NCHW: both 1x1 head convolutions + bias + ReLU, the policy FC
+// and the value FC -> ReLU -> FC -> tanh, written straight into the engine's logits / value buffers.  The board count may be
+// on the device (batch_dev), so nothing here needs the host: it replaces the heads kernel + three library GEMMs (+ their
+// at::empty allocations and output copies) of the earlier wide-board path.  A workgroup takes NB boards: their head maps
+// (NB x OC x HW floats) stay in LDS; the FC weights are streamed from global memory ONCE per workgroup - thread = one output
+// column, consecutive threads read consecutive weights of a row (coalesced), the NB map values of a row are LDS broadcasts -
+// and reused for the NB boards in registers.  The tail is 0.3 % of the network's arithmetic; what matters is that it has
+// no host dependency and no extra passes over the 64-channel activation.
+template <int OC, int NB>
+__global__ void __launch_bounds__(256) tail_nchw_kernel(const float* __restrict__ x, const float* __restrict__ hw,
+                                                        const float* __restrict__ hb, const float* __restrict__ pfc_w,
+                                                        const float* __restrict__ pfc_b, const float* __restrict__ vfc1_w,
+                                                        const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
+                                                        const float* __restrict__ vfc2_b, float* __restrict__ logits,
+                                                        float* __restrict__ value, int batch, int HW, int PC, int A, int HID,
+                                                        const unsigned* __restrict__ batch_dev) {
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+    }
+    const int n0 = (int)blockIdx.x * NB;
+    if (n0 >= batch) return;
+    extern __shared__ float tsh[];
+    float* const s_hw = tsh;                           // [OC][64] + [OC]
+    float* const s_maps = tsh + OC * 64 + OC;          // [NB][OC * HW]: policy maps first, then value maps
+    float* const s_hid = s_maps + NB * OC * HW;        // [NB][HID]
+    const int tid = (int)threadIdx.x;
+    const int nb = batch - n0 < NB ? batch - n0 : NB;
+    for (int i = tid; i < OC * 64 + OC; i += 256) s_hw[i] = i < OC * 64 ? hw[i] : hb[i - OC * 64];
+    __syncthreads();
+    // stage 1: thread = (board, cell); consecutive lanes read consecutive cells of one channel plane
+    for (int e = tid; e < nb * HW; e += 256) {
+        const int b = e / HW, cell = e - b * HW;
+        const float* xp = x + ((size_t)(n0 + b) * 64) * HW + cell;
+        float acc[OC];
+#pragma unroll
+        for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+            const float v = xp[(size_t)c * HW];
+#pragma unroll
+            for (int o = 0; o < OC; ++o) acc[o] += s_hw[o * 64 + c] * v;
+        }
+#pragma unroll
+        for (int o = 0; o < OC; ++o) {
+            const float r = acc[o] + s_hw[OC * 64 + o];
+            s_maps[b * (OC * HW) + o * HW + cell] = r > 0.0f ? r : 0.0f;
+        }
+    }
+    __syncthreads();
+    // stage 2a: policy FC, thread = output column a
+    const int PIN = PC * HW, VIN = (OC - PC) * HW;
+    for (int a = tid; a < A; a += 256) {
+        float acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
+        for (int q = 0; q < PIN; ++q) {
+            const float w = pfc_w[(size_t)q * A + a];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] += s_maps[b * (OC * HW) + q] * w;
+        }
+        const float bias = pfc_b[a];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (b < nb) logits[(size_t)(n0 + b) * A + a] = acc[b] + bias;
+    }
+    // stage 2b: value FC1 + ReLU, thread = hidden unit j; then FC2 + tanh per board
+    for (int j = tid; j < HID; j += 256) {
+        float acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
+        for (int q = 0; q < VIN; ++q) {
+            const float w = vfc1_w[(size_t)q * HID + j];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] += s_maps[b * (OC * HW) + PIN + q] * w;
+        }
+        const float bias = vfc1_b[j], w2 = vfc2_w[j];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float h = acc[b] + bias;
+            s_hid[b * HID + j] = (h > 0.0f ? h : 0.0f) * w2;
+        }
+    }
+    __syncthreads();
+    if (tid < nb) {
+        float sum = vfc2_b[0];
+        for (int j = 0; j < HID; ++j) sum += s_hid[tid * HID + j];
+        value[n0 + tid] = tanhf(sum);
+    }
+}
+
 // planes: [batch][P][H][W] (the engine's dense network batch), w: [64][P][3][3], y: layout W.  -1: no kernel for this P.
 // Stem for boards wider than 8 (Go 9x9 / 19x19; any H x W), NCHW in and out: conv3x3 (P planes -> 64 channels, padding 1) +
 // folded BatchNorm/bias + ReLU.  thread = one board cell, its 3x3xP patch in registers (the planes are read straight from
@@ -348,8 +439,14 @@ __global__ void __launch_bounds__(256) stem_nchw_kernel(const float* __restrict_
 template <int P>
 __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __restrict__ planes, const float* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             float* __restrict__ y, long long cells, int H, int W) {
+                                                             float* __restrict__ y, long long cells, int H, int W,
+                                                             const unsigned* __restrict__ batch_dev) {
     constexpr int PG = (P + 3) / 4, KS = PG * 9;
+    if (batch_dev) {                                   // the real board count is on the device; `cells` is the capacity
+        const long long real = (long long)*batch_dev * H * W;
+        cells = real < cells ? real : cells;
+        if ((long long)blockIdx.x * 64 >= cells) return;
+    }
     __shared__ __attribute__((aligned(16))) float wsh[KS * 64 * 4];          // [step][lane][channel block]
     __shared__ float scsh[2][64];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -414,17 +511,18 @@ __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __r
     }
 }
 
-extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
-                                      long long batch, int P, int H, int W, void* stream) {
+extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                          long long batch, int P, int H, int W, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     const long long cells = batch * H * W;
-    if (cells * P * 4 < 0x40000000LL && !getenv("SPRL_STEM_VALU")) {
+    if (batch_dev && (cells * P * 4 >= 0x40000000LL || (P != 3 && P != 17))) return -1;      // only the MFMA form reads the count
+    if (cells * P * 4 < 0x40000000LL && (batch_dev || !getenv("SPRL_STEM_VALU"))) {
         long long blocks = (cells / 16 + 3) / 4;
         if (blocks > 256 * 6) blocks = 256 * 6;        // grid-stride over 16-cell tiles: the weight fragments are staged once per workgroup
         if (blocks < 1) blocks = 1;
         const dim3 g((unsigned)blocks), bl(256);
-        if (P == 3) hipLaunchKernelGGL(stem_mfma_nchw_kernel<3>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W);
-        else if (P == 17) hipLaunchKernelGGL(stem_mfma_nchw_kernel<17>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W);
+        if (P == 3) hipLaunchKernelGGL(stem_mfma_nchw_kernel<3>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W, batch_dev);
+        else if (P == 17) hipLaunchKernelGGL(stem_mfma_nchw_kernel<17>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W, batch_dev);
         else return -1;
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
@@ -433,6 +531,10 @@ extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const
     else if (P == 17) hipLaunchKernelGGL(stem_nchw_kernel<17>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                      long long batch, int P, int H, int W, void* stream) {
+    return sprl_stem_conv3x3_nchw_dev(planes, w, scale, shift, y, batch, P, H, W, nullptr, stream);
 }
 
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
@@ -537,5 +639,30 @@ extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* h
         hipLaunchKernelGGL((tail_kernel<2, 1>), grid, block, 0, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
                            value, batch, H, W, A, HID, batch_dev, maps_in);
     else return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// x: trunk output NCHW [batch][64][H*W]; hw/hb: [PC + VC][64] / [PC + VC] head convolutions (policy rows first); pfc_w: [PC*H*W][A]
+// (transposed Linear weight), vfc1_w: [VC*H*W][HID], vfc2_w: [HID]; logits: [batch][A], value: [batch]; batch_dev: optional
+// device pointer to the real board count (<= batch).  -1: shape not covered (the caller falls back to the library GEMMs).
+extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
+                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* logits,
+                              float* value, int batch, int H, int W, int PC, int VC, int A, int HID, const unsigned* batch_dev,
+                              void* stream) {
+    if (batch <= 0) return 0;
+    const int OC = PC + VC, HW = H * W;
+    if (OC != 3 || PC != 2 || HID > 256) return -1;
+    const bool big = OC * HW > 512;                    // 19x19: 1083 floats of maps per board -> 8 boards per workgroup
+    const int NB = big ? 8 : 16;
+    const size_t lds = (size_t)(OC * 64 + OC + NB * OC * HW + NB * HID) * sizeof(float);
+    if (lds > 64 * 1024) return -1;
+    const dim3 grid((unsigned)((batch + NB - 1) / NB)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (big)
+        hipLaunchKernelGGL((tail_nchw_kernel<3, 8>), grid, block, lds, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
+                           value, batch, HW, PC, A, HID, batch_dev);
+    else
+        hipLaunchKernelGGL((tail_nchw_kernel<3, 16>), grid, block, lds, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
+                           value, batch, HW, PC, A, HID, batch_dev);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

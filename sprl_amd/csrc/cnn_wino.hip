@@ -323,48 +323,96 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 
 // ---------------------------------------------------------------------------------------------------
 // General boards (any H x W, e.g. Go 9x9 and 19x19), plain NCHW activations in and out: same Winograd / MFMA core as
-// version 2, but a workgroup takes 16 consecutive TILES of the batch (boards are ceil(H/4) x ceil(W/4) tiles, a tile's
-// 6x6 input patch reaches into its neighbours), so the loader gathers the 36 patch values of every (channel, tile) straight
-// from global memory into LDS patches [slot][tile][37] (slot stride 592 = 16 mod 32: a 32-lane bank group reads 32 banks).
-// Used by the library-convolution path for its trunk convolutions (torch_eval.cpp) - the stem and the heads stay as they are.
+// version 2, but a workgroup takes 16 consecutive TILES of the batch (boards are ceil(H/M) x ceil(W/M) tiles, a tile's
+// (M+2) x (M+2) input patch reaches into its neighbours), so the loader gathers the patch values of every (channel, tile)
+// straight from global memory into LDS patches [slot][tile][PS] (PS odd, slot stride = 16 mod 32: a 32-lane bank group reads
+// 32 banks).
+//
+// Two tilings, chosen by the host per board size (sprl_wino_nchw_tile):
+//   M = 4: F(4x4, 3x3), 36 transform positions per tile - 19x19 (5x5 tiles, 361 of 400 cells useful);
+//   M = 3: F(3x3, 3x3), 25 transform positions per tile - 9x9 (3x3 tiles, no padding: 225 position-products per board where
+//          F(4x4) needs 324).  Interpolation points 0, 1, -1, 2, inf:
+//            B^T = [2 -1 -2 1 0; 0 2 1 -1 0; 0 -2 3 -1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
+//            G   = [1/2 0 0; 1/2 1/2 1/2; 1/6 -1/6 1/6; 1/6 1/3 2/3; 0 0 1]       (torch_eval.cpp: wino_transform)
+//            A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]
 // ---------------------------------------------------------------------------------------------------
-constexpr int PS_G = 37, SS_G = 16 * PS_G;            // patch stride, channel-slot stride
-constexpr int IN_BUF_G = 8 * SS_G;
-constexpr int LDS_FLOATS_G = 2 * IN_BUF_G + 4 * V_G2;  // 74.8 KB: two workgroups per CU
-constexpr int NLD_G = (8 * 16 * 36) / NTHR2;          // 18 patch values per thread and chunk
 constexpr unsigned SLACK_G = 32;                      // bytes that must be readable behind x and res (see the kernel)
 
-__global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float* __restrict__ x, const float* __restrict__ u,
+template <int M>
+struct NchwGeom {
+    static constexpr int PT = M + 2;                  // patch width
+    static constexpr int NP = PT * PT;                // transform positions
+    static constexpr int NQ = (NP + 3) / 4;           // filter quads (16-byte A loads of four positions)
+    static constexpr int PS = M == 4 ? 37 : 25;       // patch stride (odd)
+    static constexpr int SS = 16 * PS;                // channel-slot stride (== 16 mod 32)
+    static constexpr int IN_BUF = 8 * SS;
+    static constexpr int VG = NP * 64;                // V of one group: [p][c_sub][16 tiles]
+    static constexpr int LDS_FLOATS = 2 * IN_BUF + 4 * VG;      // M = 4: 74.8 KB, M = 3: 50.6 KB
+    static constexpr int R0 = 3;                      // transform rows of producer half 0 (half 1: PT - 3)
+    static constexpr int NLD = R0 * PT;               // patch values a loader thread holds (half 1 of M = 3 uses 2 rows of them)
+};
+
+// Y = A^T m A for one (channel, tile), F(3x3, 3x3): rows of the 3x3 output
+__device__ __forceinline__ void inverse_transform3(const float (&m)[5][5], float (&o)[3][3]) {
+    float tm[3][5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        const float s12 = m[1][b] + m[2][b], d12 = m[1][b] - m[2][b];
+        tm[0][b] = m[0][b] + s12 + m[3][b];
+        tm[1][b] = d12 + 2.0f * m[3][b];
+        tm[2][b] = s12 + 4.0f * m[3][b] + m[4][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float s12 = tm[i][1] + tm[i][2], d12 = tm[i][1] - tm[i][2];
+        o[i][0] = tm[i][0] + s12 + tm[i][3];
+        o[i][1] = d12 + 2.0f * tm[i][3];
+        o[i][2] = s12 + 4.0f * tm[i][3] + tm[i][4];
+    }
+}
+
+template <int M, int OCC>
+__global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                                    int H, int W, int relu) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS_G];
+                                                                    int H, int W, int relu, const unsigned* __restrict__ batch_dev) {
+    using Gm = NchwGeom<M>;
+    constexpr int PT = Gm::PT, NP = Gm::NP, NQ = Gm::NQ, PS = Gm::PS, SS = Gm::SS, IN_BUF = Gm::IN_BUF, VG = Gm::VG, NLD = Gm::NLD;
+    // batch_dev != null: the number of boards is on the device (the engine's leaf count of this round), `batch` is the capacity
+    // the grid was sized for; workgroups whose 16 tiles lie past the real count leave at once
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+    }
+    const int TX = (W + M - 1) / M, TY = (H + M - 1) / M, TPB = TX * TY;
+    if ((long long)blockIdx.x * 16 >= (long long)batch * TPB) return;
+    __shared__ __attribute__((aligned(16))) float lds[Gm::LDS_FLOATS];
     float* const in_buf = lds;
-    float* const v_buf = lds + 2 * IN_BUF_G;
+    float* const v_buf = lds + 2 * IN_BUF;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c_sub = lane >> 4, tl = lane & 15;
     const int gl = wave & 1, wa = wave >> 1;
     const int kb = wave;
-    const int TX = (W + 3) >> 2, TY = (H + 3) >> 2, TPB = TX * TY;
     const int HW = H * W;
     // this thread's tile (the same one as loader, tid & 15, and as MFMA column / output lane, lane & 15)
     const int total_tiles = batch * TPB;              // the host keeps batch * tiles-per-board below 2^31
     const int tg = (int)blockIdx.x * 16 + tl;
     const int t_n = tg < total_tiles ? tg / TPB : -1;
     const int t_tt = tg < total_tiles ? tg % TPB : 0;
-    const int t_row0 = 4 * (t_tt / TX), t_col0 = 4 * (t_tt % TX);
+    const int t_row0 = M * (t_tt / TX), t_col0 = M * (t_tt % TX);
 
-    f4 acc[36];
+    f4 acc[NP];
 #pragma unroll
-    for (int q = 0; q < 36; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int q = 0; q < NP; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
 
-    // chunk = groups 2c, 2c+1: 8 channel slots x 16 tiles x 36 patch values.  Loader thread = (tile, slot, half): the
-    // three patch rows 3 half .. 3 half + 2 of one (channel slot, tile), 18 values
+    // chunk = groups 2c, 2c+1: 8 channel slots x 16 tiles x NP patch values.  Loader thread = (tile, slot, half): the patch
+    // rows 3 half .. 3 half + 2 of one (channel slot, tile) (M = 3, half 1: rows 3 and 4)
     const int ld_tile = tl, ld_slot = (tid >> 4) & 7, ld_half = tid >> 7;
     const int ld_n = t_n;
     const int ld_row = t_row0 - 1 + 3 * ld_half, ld_col = t_col0 - 1;
-    const int ld_lds = ld_slot * SS_G + ld_tile * PS_G + 18 * ld_half;
+    const int ld_lds = ld_slot * SS + ld_tile * PS + 3 * PT * ld_half;
+    const int ld_rows = (M == 3 && ld_half == 1) ? 2 : 3;
     // Every global access goes through a buffer descriptor with a per-lane byte offset; an element off the board (or a tile
     // past the batch) gets bit 31 set in its offset, which the hardware range check answers with 0 for loads and drops for
     // stores (the host keeps the tensors below 2 GiB) - no predicated loads, no branches, no 64-bit address arithmetic.
@@ -372,24 +420,24 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
     const unsigned act_bytes = (unsigned)batch * 64u * (unsigned)HW * 4u;
     // the input descriptor starts 16 bytes before x: a patch's first column is col0 - 1, so with the bias no offset is ever
     // negative (a negative per-lane offset plus a positive instruction offset must not depend on how the range check wraps)
-    // A patch row (6 floats) is one 16-byte + one 8-byte load and a residual row one 16-byte load, at 4-byte alignment; at a
-    // board's edge they run into the next row / plane (those values are replaced by zeros below / never stored) and at the very
-    // end of the tensor up to 20 bytes past it, at its very start 4 bytes before it (the left neighbour of column 0): x must be
-    // readable from 16 bytes before its start, x and res for 32 bytes beyond their end (SLACK_G).
+    // A patch row (6 or 5 floats) is one 16-byte + one 8- or 4-byte load and a residual row one 16-byte load, at 4-byte alignment;
+    // at a board's edge they run into the next row / plane (those values are replaced by zeros below / never stored) and at the
+    // very end of the tensor up to 20 bytes past it, at its very start 4 bytes before it (the left neighbour of column 0): x must
+    // be readable from 16 bytes before its start, x and res for 32 bytes beyond their end (SLACK_G).
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x - 16), 0, act_bytes + 16u + SLACK_G, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes + SLACK_G : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, act_bytes, 0x00020000);
     int ld_rowoff[3];
-    bool ld_colok[6];
+    bool ld_colok[PT];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) ld_colok[j] = ld_col + j >= 0 && ld_col + j < W;
+    for (int j = 0; j < PT; ++j) ld_colok[j] = ld_col + j >= 0 && ld_col + j < W;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int row = ld_row + i;
         // (board, channel slot 0 of the chunk, row, first patch column) in bytes; the chunk's channel is added per load
-        ld_rowoff[i] = (ld_n >= 0 && row >= 0 && row < H) ? ((ld_n * 64) * HW + row * W + ld_col) * 4 + 16 : OOB;
+        ld_rowoff[i] = (ld_n >= 0 && row >= 0 && row < H && i < ld_rows) ? ((ld_n * 64) * HW + row * W + ld_col) * 4 + 16 : OOB;
     }
-    float pre[NLD_G];
+    float pre[NLD];
     auto gload = [&](int chunk) {
         const int g = 2 * chunk + (ld_slot >> 2);
         const int k = 16 * (g >> 2) + 4 * (ld_slot & 3) + (g & 3);
@@ -397,77 +445,121 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const f4 a4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_rowoff[i] + koff, 0, 0));
-            const f2 a2 = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rx, ld_rowoff[i] + koff + 16, 0, 0));
-            pre[i * 6 + 0] = a4[0]; pre[i * 6 + 1] = a4[1]; pre[i * 6 + 2] = a4[2]; pre[i * 6 + 3] = a4[3];
-            pre[i * 6 + 4] = a2[0]; pre[i * 6 + 5] = a2[1];
+            pre[i * PT + 0] = a4[0]; pre[i * PT + 1] = a4[1]; pre[i * PT + 2] = a4[2]; pre[i * PT + 3] = a4[3];
+            if (M == 4) {
+                const f2 a2 = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rx, ld_rowoff[i] + koff + 16, 0, 0));
+                pre[i * PT + 4] = a2[0]; pre[i * PT + (M == 4 ? 5 : 4)] = a2[1];
+            } else {
+                pre[i * PT + 4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ld_rowoff[i] + koff + 16, 0, 0));
+            }
         }
     };
     auto lstore = [&](float* buf) {
 #pragma unroll
-        for (int q = 0; q < NLD_G; ++q) buf[ld_lds + q] = ld_colok[q % 6] ? pre[q] : 0.0f;      // columns off the board
+        for (int q = 0; q < NLD; ++q)
+            if (M == 4 || q < 2 * PT || ld_half == 0) buf[ld_lds + q] = ld_colok[q % PT] ? pre[q] : 0.0f;      // columns off the board
     };
-    const int patch0 = (gl * 4 + c_sub) * SS_G + tl * PS_G + wa * 6;
-    const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
+    const int patch0 = (gl * 4 + c_sub) * SS + tl * PS + wa * 3 * PT;
+    const int vdst0 = gl * VG + (3 * wa) * PT * 64 + lane;
     auto produce = [&](int c) {
-        const float* pp = in_buf + (c & 1) * IN_BUF_G + patch0;
-        float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
-        float wr[3][6];
-        if (wa == 0) {
+        const float* pp = in_buf + (c & 1) * IN_BUF + patch0;
+        float* vd = v_buf + (c & 1) * 2 * VG + vdst0;
+        if (M == 4) {
+            float wr[3][6];
+            if (wa == 0) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
-                const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
-                wr[0][j] = 4.0f * e0 - 5.0f * e2 + e4;
-                wr[1][j] = p + q;
-                wr[2][j] = p - q;
+                for (int j = 0; j < 6; ++j) {
+                    const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
+                    const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                    wr[0][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                    wr[1][j] = p + q;
+                    wr[2][j] = p - q;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
+                    const float p = e3 - e1, q = 2.0f * (e2 - e0);
+                    wr[0][j] = p + q;
+                    wr[1][j] = p - q;
+                    wr[2][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+                const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
+                vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
+                vd[(r * 6 + 1) * 64] = p + q;
+                vd[(r * 6 + 2) * 64] = p - q;
+                vd[(r * 6 + 3) * 64] = p2 + q2;
+                vd[(r * 6 + 4) * 64] = p2 - q2;
+                vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
             }
         } else {
+            // F(3x3,3x3): half 0 builds transform rows 0..2 (from patch rows 0..3), half 1 rows 3..4 (from patch rows 1..4, i.e.
+            // pp already points at patch row 3: rows 1..4 are pp[-2 PT] .. pp[PT])
+            float wr[3][5];
+            if (wa == 0) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
-                const float p = e3 - e1, q = 2.0f * (e2 - e0);
-                wr[0][j] = p + q;
-                wr[1][j] = p - q;
-                wr[2][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                for (int j = 0; j < 5; ++j) {
+                    const float e0 = pp[j], e1 = pp[5 + j], e2 = pp[10 + j], e3 = pp[15 + j];
+                    const float t = e3 - e1;                               // B^T rows: [2 -1 -2 1 0], [0 2 1 -1 0], [0 -2 3 -1 0]
+                    wr[0][j] = 2.0f * (e0 - e2) + t;
+                    wr[1][j] = (e2 + e1) - t;
+                    wr[2][j] = 3.0f * e2 - 2.0f * e1 - e3;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const float e1 = pp[j - 10], e2 = pp[j - 5], e3 = pp[j], e4 = pp[5 + j];
+                    wr[0][j] = e3 - e1;                                    // [0 -1 0 1 0]
+                    wr[1][j] = 2.0f * (e1 - e3) - e2 + e4;                 // [0 2 -1 -2 1]
+                    wr[2][j] = 0.0f;
+                }
             }
-        }
+            const int nr = wa == 0 ? 3 : 2;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
-            const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
-            vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
-            vd[(r * 6 + 1) * 64] = p + q;
-            vd[(r * 6 + 2) * 64] = p - q;
-            vd[(r * 6 + 3) * 64] = p2 + q2;
-            vd[(r * 6 + 4) * 64] = p2 - q2;
-            vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
+            for (int r = 0; r < 3; ++r) {
+                if (r < nr) {
+                    const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4];
+                    const float t = w3 - w1;
+                    vd[(r * 5 + 0) * 64] = 2.0f * (w0 - w2) + t;
+                    vd[(r * 5 + 1) * 64] = (w2 + w1) - t;
+                    vd[(r * 5 + 2) * 64] = 3.0f * w2 - 2.0f * w1 - w3;
+                    vd[(r * 5 + 3) * 64] = t;
+                    vd[(r * 5 + 4) * 64] = 2.0f * (w1 - w3) - w2 + w4;
+                }
+            }
         }
     };
     const f4* ua = (const f4*)u + kb * 64 + lane;
-    f4 a[9];
+    f4 a[NQ];
     auto aload = [&](int s, int k) { a[k] = ua[(size_t)k * (16 * 4 * 64) + s * 256]; };
     auto mma = [&](const float* vg, int k) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float b = vg[(k * 4 + q) * 64 + lane];
-            acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
+            if (k * 4 + q < NP) {
+                const float b = vg[(k * 4 + q) * 64 + lane];
+                acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
+            }
         }
     };
     auto phase = [&](int c) {
-        const float* vs = v_buf + (c & 1) * 2 * V_G2;
+        const float* vs = v_buf + (c & 1) * 2 * VG;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
             const int s = 2 * c + g2;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                mma(vs + g2 * V_G2, k);
+            for (int k = 0; k < NQ; ++k) {
+                mma(vs + g2 * VG, k);
                 if (s + 1 < 16) aload(s + 1, k);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < 8) produce(c + 1);
         if (c + 2 < 8) {
-            lstore(in_buf + (c & 1) * IN_BUF_G);
+            lstore(in_buf + (c & 1) * IN_BUF);
             if (c + 3 < 8) gload(c + 3);
         }
         __syncthreads();
@@ -477,8 +569,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
     lstore(in_buf);
     gload(1);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) aload(0, k);
-    lstore(in_buf + IN_BUF_G);
+    for (int k = 0; k < NQ; ++k) aload(0, k);
+    lstore(in_buf + IN_BUF);
     gload(2);
     __syncthreads();
     produce(0);
@@ -487,35 +579,36 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_nchw_kernel(const float*
 
     // ---- inverse transform in registers + epilogue, NCHW ----
     // byte offset of (board, channel 0, row0 + i, col0) per output row, bit 31 set when the row is off the board / past the batch
-    int o_rowoff[4], o_colsel[4];
+    int o_rowoff[M], o_colsel[M];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o_rowoff[i] = (t_n >= 0 && t_row0 + i < H) ? ((t_n * 64) * HW + (t_row0 + i) * W + t_col0) * 4 : OOB;
+    for (int i = 0; i < M; ++i) o_rowoff[i] = (t_n >= 0 && t_row0 + i < H) ? ((t_n * 64) * HW + (t_row0 + i) * W + t_col0) * 4 : OOB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o_colsel[j] = (t_col0 + j < W) ? 0 : OOB;
+    for (int j = 0; j < M; ++j) o_colsel[j] = (t_col0 + j < W) ? 0 : OOB;
     // residual values of output component r (channel 16 kb + 4 c_sub + r), requested one component ahead of their use
-    f4 rres[2][4];
-    auto rload = [&](int r, f4 (&dst)[4]) {
+    f4 rres[2][M];
+    auto rload = [&](int r, f4 (&dst)[M]) {
         const int koff = (16 * kb + 4 * c_sub + r) * HW * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, o_rowoff[i] + koff, 0, 0));
+        for (int i = 0; i < M; ++i) dst[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, o_rowoff[i] + koff, 0, 0));
     };
     rload(0, rres[0]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         __builtin_amdgcn_sched_barrier(0);
         if (r + 1 < 4) rload(r + 1, rres[(r + 1) & 1]);
-        float m[6][6];
+        float m[PT][PT];
 #pragma unroll
-        for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = acc[p][r];
-        float o[4][4];
-        inverse_transform(m, o);
+        for (int p = 0; p < NP; ++p) m[p / PT][p % PT] = acc[p][r];
+        float o[M][M];
+        if constexpr (M == 4) inverse_transform(m, o);
+        else inverse_transform3(m, o);
         const int k = 16 * kb + 4 * c_sub + r;
         const float sc = scale[k], sh = shift[k];
         const int koff = k * HW * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < M; ++j) {
                 float v = o[i][j] * sc + sh + rres[r & 1][i][j];
                 if (relu) v = v > 0.0f ? v : 0.0f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ((o_rowoff[i] + koff) | o_colsel[j]) + j * 4, 0, 0);
@@ -566,18 +659,44 @@ extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const floa
     return launch_conv64<1>(x, u, scale, shift, res, nullptr, batch, H, W, 1, batch_dev, ha, stream);
 }
 
-// Any board size, NCHW activations [batch][64][H][W] in and out (res may be null; y must not alias x); same weights `u`.
+// Any board size, NCHW activations [batch][64][H][W] in and out (res may be null; y must not alias x).  `u`: the weights in the
+// Winograd domain of the tiling sprl_wino_nchw_tile(H, W) selects (torch_eval.cpp: wino_transform with that tile size).
 // x must be readable from 16 bytes before its start, x and res for sprl_wino_nchw_slack() bytes behind their end (patch rows
-// are fetched 16 + 8 bytes at a time, starting one column left of the tile).
+// are fetched 16 + 8 bytes at a time, starting one column left of the tile).  batch_dev: optional device pointer to the real
+// board count (<= batch, the capacity the buffers and the grid are sized for).
 extern "C" int sprl_wino_nchw_slack(void) { return (int)SLACK_G; }
-extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float* scale, const float* shift, const float* res,
-                                     float* y, int batch, int H, int W, int relu, void* stream) {
+// output tile size of the any-board kernel for an H x W board: 3 (F(3x3,3x3), 25 positions per tile) when that needs fewer
+// position-products than 4 (F(4x4,3x3), 36 per tile) - 9x9: 9 x 25 = 225 against 9 x 36 = 324; 19x19: 4 (900 against 1225)
+extern "C" int sprl_wino_nchw_tile(int H, int W) {
+    if (getenv("SPRL_WINO_NCHW_TILE")) return atoi(getenv("SPRL_WINO_NCHW_TILE")) == 3 ? 3 : 4;
+    const long long w4 = (long long)((H + 3) / 4) * ((W + 3) / 4) * 36, w3 = (long long)((H + 2) / 3) * ((W + 2) / 3) * 25;
+    return w3 < w4 ? 3 : 4;
+}
+extern "C" int sprl_wino_conv64_nchw_tiled(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                           float* y, int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
-    if (H < 1 || W < 1 || H > 64 || W > 64) return -1;
-    const long long tiles = (long long)batch * ((H + 3) / 4) * ((W + 3) / 4);
+    if (H < 1 || W < 1 || H > 64 || W > 64 || (tile != 3 && tile != 4)) return -1;
+    const long long tiles = (long long)batch * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
     if (tiles > 0x7fffffffLL - 16) return -1;
     if ((long long)batch * 64 * H * W * 4 >= 0x7fffff00LL) return -1;   // per-lane byte offsets: bit 31 marks "off the board"
     const dim3 grid((unsigned)((tiles + 15) / 16)), block(NTHR2);
-    hipLaunchKernelGGL(wino_conv64_nchw_kernel, grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu);
+    // F(3x3): 50 KB of LDS per workgroup, so three fit a CU if the kernel is held to 168 registers (11 of them then spill);
+    // SPRL_WINO_F3_OCC=2 selects the two-per-CU build without spills (measured: DESIGN.md section 5)
+    static const int f3_occ = getenv("SPRL_WINO_F3_OCC") ? atoi(getenv("SPRL_WINO_F3_OCC")) : 3;
+    if (tile == 4)
+        hipLaunchKernelGGL((wino_conv64_nchw_kernel<4, 2>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev);
+    else if (f3_occ == 2)
+        hipLaunchKernelGGL((wino_conv64_nchw_kernel<3, 2>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev);
+    else
+        hipLaunchKernelGGL((wino_conv64_nchw_kernel<3, 3>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// F(4x4,3x3) tiling, as before
+extern "C" int sprl_wino_conv64_nchw_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                         float* y, int batch, int H, int W, int relu, const unsigned* batch_dev, void* stream) {
+    return sprl_wino_conv64_nchw_tiled(x, u, scale, shift, res, y, batch, H, W, relu, 4, batch_dev, stream);
+}
+extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                     float* y, int batch, int H, int W, int relu, void* stream) {
+    return sprl_wino_conv64_nchw_tiled(x, u, scale, shift, res, y, batch, H, W, relu, 4, nullptr, stream);
 }

@@ -492,7 +492,10 @@ int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len) {
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2 && e->g.rows <= 8 && e->g.cols <= 8)
                            ? "hand-written gfx950 CNN: MFMA stem + Winograd F(4x4,3x3) fp32-MFMA trunk with fused BN/residual/ReLU + fused heads/FC tail"
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model) == 2)
-                           ? "hand-written gfx950 CNN for any board: NCHW stem kernel + Winograd F(4x4,3x3) fp32-MFMA trunk + 1x1 heads kernel, rocBLAS FC tail"
+                           ? (e->dev_batch ? "hand-written gfx950 CNN for any board: NCHW MFMA stem + Winograd fp32-MFMA trunk + fused heads/FC tail, "
+                                             "batch size read on the device (no host round trip per search round)"
+                                           : "hand-written gfx950 CNN for any board: NCHW MFMA stem + Winograd fp32-MFMA trunk + fused heads/FC tail, "
+                                             "batch size on the host")
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model))
                            ? "LibTorch-ROCm: MIOpen convolutions + fused bias/BN/ReLU epilogue kernel"
                            : "LibTorch-ROCm: TorchScript graph (bias hoisted for the JIT fuser)";

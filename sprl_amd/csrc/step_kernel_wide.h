@@ -33,23 +33,30 @@ struct NodeHdrW {
     uint16_t action, depth;
 };
 
+// Per-wave LDS.  The positions of the line (real game + current descent) are NOT here: they live in HBM
+// (EngineParams::hist_boards, one ring per slot) and only their 64-bit signatures sit in LDS.  At 19x19 the position history
+// alone was 70 KB per wave (and the per-group stone masks another 18 KB), which left room for ONE wave per CU; now a 19x19 wave
+// needs 23 KB and six of them share a CU.
 template <class G>
 struct WaveLdsW {
     uint32_t path[G::MAX_DEPTH];
-    Bits<G::WORDS> hist[G::HIST_CAP][2];
-    uint64_t hsig[G::HIST_CAP];               // pos_sig of hist[i]: the superko test compares signatures first
+    uint64_t hsig[G::HIST_CAP];               // pos_sig of position i of the line: the superko test compares signatures, and
+                                              // whole positions (from the ring in HBM) only where a signature matches
     Bits<G::WORDS> leaf_hist[SPRL_MAXQ][G::HIST][2];
     uint32_t leaf_size[SPRL_MAXQ];
-    float xf[G::STRIPS * 64];                 // cross-strip exchange: one float / u32 / group mask per point
+    float xf[G::STRIPS * 64];                 // cross-strip exchange: one float / u32 per point
     uint32_t xu[G::STRIPS * 64];
     uint32_t xl[G::STRIPS * 64];              // liberties per group label
-    Bits<G::WORDS> xg[G::STRIPS * 64];
+    uint32_t xs[G::STRIPS * 64][2];           // label form: signature (lo, hi) of the stones of each opponent group in atari
+    Bits<G::WORDS> xg[G::STRIPS <= 2 ? G::STRIPS * 64 : 1];    // flood form (boards up to two strips): stone mask per group
     uint32_t fcache[SPRL_FCACHE];             // recycled node ids ready for reuse (GameCtl::fcache while the slot runs)
 };
 
 // 64-bit signature of a position (xor of rotated words): equal positions have equal signatures, so the positional-superko test
 // only has to compare whole bit sets (2 x WORDS words) with the ancestors whose signature matches the candidate's - exact as
-// before, ~WORDS times fewer LDS reads and compares per ancestor.
+// before.  The signature is xor-linear in the stones (every stone contributes one bit, stone_sig), so the signature of "this
+// position + a stone at a - the captured groups" follows from 64-bit group signatures without building the position - what the
+// reference does with Zobrist hashes (games/GoNode.cpp:186-227), except that a match is then verified on the whole position.
 template <int W>
 SPRL_DEV uint64_t pos_sig(const Bits<W>& a, const Bits<W>& b) {
     uint64_t s = 0;
@@ -60,10 +67,16 @@ SPRL_DEV uint64_t pos_sig(const Bits<W>& a, const Bits<W>& b) {
     }
     return s;
 }
+// contribution of one stone at point a of Player `plane` to pos_sig
+SPRL_DEV uint64_t stone_sig(int a, int plane) {
+    const int w = a >> 6, r = (11 * w + (plane ? 33 : 1)) & 63;
+    return 1ull << (((a & 63) + r) & 63);
+}
+// position `at` of the line: the bit sets go to the slot's ring in HBM, the signature to LDS (one lane calls this)
 template <class G>
-SPRL_DEV void hist_put(WaveLdsW<G>* lds, int at, const Bits<G::WORDS>& p0, const Bits<G::WORDS>& p1) {      // one lane calls this
-    lds->hist[at][0] = p0;
-    lds->hist[at][1] = p1;
+SPRL_DEV void hist_put(WaveLdsW<G>* lds, Bits<G::WORDS>* ring, int at, const Bits<G::WORDS>& p0, const Bits<G::WORDS>& p1) {
+    ring[2 * at] = p0;
+    ring[2 * at + 1] = p1;
     lds->hsig[at] = pos_sig<G::WORDS>(p0, p1);
 }
 
@@ -80,6 +93,7 @@ template <class G> SPRL_DEV NodeHdrW<G::WORDS>* hdr_of(uint8_t* n) { return (Nod
 struct GameW {
     Pcg32 rng;
     uint8_t* abase;
+    void* ring;                  // Bits<WORDS>[HIST_CAP][2]: positions of the line (this slot's part of EngineParams::hist_boards)
     uint32_t arena, root, n_alloc, epoch, root_player, game_id, status;
     uint32_t rstack_n, fc_n;     // node recycling: reclaim stack height, ready recycled ids (as step_kernel.h)
     float rootN, rootW;
@@ -199,7 +213,7 @@ SPRL_DEV PosW<G::WORDS> pos_of(const NodeHdrW<G::WORDS>& h) {
 // liberties, neighbour inspection through the LDS exchange, exact positional-superko compare with the ancestors.
 // Small boards (up to two strips): every stone lane flood-fills its own group as a bit set - fewer, wider steps.
 template <class G>
-SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, int n_hist) {
+SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, const Bits<G::WORDS>* ring, int n_hist) {
     using BB = Bits<G::WORDS>;
     const int l = wv::lane();
     const BB own = c.player ? c.p1 : c.p0, opp = c.player ? c.p0 : c.p1;
@@ -249,7 +263,7 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>
             bool repeat = false;
             const uint64_t sg = pos_sig<G::WORDS>(np0, np1);
             for (int i = 0; i < n_hist; ++i)
-                if (lds->hsig[i] == sg) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
+                if (lds->hsig[i] == sg) repeat |= (ring[2 * i] == np0) && (ring[2 * i + 1] == np1);
             ok = has_libs && !repeat;
         }
         const uint64_t m = wv::ballot(ok);
@@ -261,9 +275,12 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>
 // Large boards: per-lane bit sets would need 2 x STRIPS x WORDS registers and one wide dilate per step; groups are
 // labelled instead (measured at 19x19: 3.6-4.9x faster than the flood form; at 9x9 the flood form is 25 % faster).
 template <class G>
-SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, int n_hist, int form) {
-    // form: 0 = by board size (flood up to two strips, labels above), 1 = labels, 2 = flood (tests run both on every size)
-    if (form == 2 || (form == 0 && G::STRIPS <= 2)) return go_legal_mask_flood<G>(c, lds, n_hist);
+SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, const Bits<G::WORDS>* ring, int n_hist, int form) {
+    // form: 0 = by board size (flood up to two strips, labels above), 1 = labels, 2 = flood (tests run both forms on the boards
+    // of up to two strips; the per-group stone masks of the flood form have no room in LDS on larger boards)
+    if constexpr (G::STRIPS <= 2) {
+        if (form == 2 || form == 0) return go_legal_mask_flood<G>(c, lds, ring, n_hist);
+    }
     using BB = Bits<G::WORDS>;
     const int l = wv::lane();
     const BB own = c.player ? c.p1 : c.p0, opp = c.player ? c.p0 : c.p1;
@@ -279,6 +296,8 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds,
         colr[st] = (uint8_t)(on && own.test(a) ? 1 : (on && opp.test(a) ? 2 : 0));
         lab[st] = colr[st] ? (uint32_t)a : 0xFFFFu;
         lds->xl[st * 64 + l] = 0;
+        lds->xs[st * 64 + l][0] = 0;
+        lds->xs[st * 64 + l][1] = 0;
     }
     for (;;) {
         for (int st = 0; st < WS; ++st) lds->xu[st * 64 + l] = lab[st];
@@ -324,25 +343,37 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds,
         }
     }
     wv::sync();
-    // 3. stone masks of the opponent groups in atari (the only ones a move can capture), one wave-wide ballot pass each
+    // 3. signatures of the opponent groups in atari (the only ones a move can capture): every stone of such a group xors its
+    //    contribution into the group's entry.  Nothing to do while no group is in atari (most of the game).
+    bool in_atari[WS];
+    uint64_t any_atari = 0;
     for (int st = 0; st < WS; ++st) {
-        uint64_t reps = wv::ballot(colr[st] == 2 && lab[st] == (uint32_t)(st * 64 + l) && lds->xl[st * 64 + l] == 1u);
-        for (; reps; reps &= reps - 1) {
-            const uint32_t rep = (uint32_t)(st * 64 + wv::ctz64(reps));
-            BB gmask;
-            for (int s2 = 0; s2 < WS; ++s2) gmask.w[s2] = wv::ballot(colr[s2] == 2 && lab[s2] == rep);
-            if (l == 0) lds->xg[rep] = gmask;
-        }
+        in_atari[st] = colr[st] == 2 && lds->xl[lab[st]] == 1u;
+        any_atari |= wv::ballot(in_atari[st]);
     }
-    wv::sync();
+    if (any_atari) {
+        for (int st = 0; st < WS; ++st)
+            if (in_atari[st]) {
+                const uint64_t sg = stone_sig(st * 64 + l, c.player ? 0 : 1);          // the opponent's plane
+                wv::atomic_xor_u32(&lds->xs[lab[st]][0], (uint32_t)sg);
+                wv::atomic_xor_u32(&lds->xs[lab[st]][1], (uint32_t)(sg >> 32));
+            }
+        wv::sync();
+    }
+    // 4. every empty point: liberties after the move, signature of the position it would give, signature lookup in the line.
+    //    A point whose signature matches an ancestor's is a SUSPECT; suspects are verified on whole positions below.
+    const uint64_t cur_sig = pos_sig<G::WORDS>(c.p0, c.p1);
     BB legal = BB::zero();
+    uint64_t suspect[WS];
     for (int st = 0; st < WS; ++st) {
         const int a = st * 64 + l;
-        bool ok = false;
+        bool ok = false, sus = false;
         if (a < G::CELLS && empty.test(a)) {
             const int row = a / G::COLS, col = a % G::COLS;
             bool has_libs = false;
-            BB cap = BB::zero();
+            uint32_t capg[4];
+            int nc = 0;
+            uint64_t sg = cur_sig ^ stone_sig(a, c.player);
             for (int d = 0; d < 4; ++d) {
                 const bool valid = d == 0 ? row > 0 : d == 1 ? col > 0 : d == 2 ? row < G::ROWS - 1 : col < G::COLS - 1;
                 if (!valid) continue;
@@ -351,20 +382,50 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds,
                 else {
                     const uint32_t g = lds->xu[nb], libs = lds->xl[g];
                     if (own.test(nb)) { if (libs > 1) has_libs = true; }
-                    else if (libs == 1) { has_libs = true; cap = cap | lds->xg[g]; }
+                    else if (libs == 1) {
+                        has_libs = true;
+                        bool dup = false;
+                        for (int k = 0; k < nc; ++k) dup |= capg[k] == g;
+                        if (!dup) {                                   // a group touching the point twice is captured once
+                            capg[nc++] = g;
+                            sg ^= (uint64_t)lds->xs[g][0] | ((uint64_t)lds->xs[g][1] << 32);
+                        }
+                    }
                 }
+            }
+            if (has_libs) {
+                for (int i = 0; i < n_hist; ++i) sus |= lds->hsig[i] == sg;
+            }
+            ok = has_libs;
+        }
+        legal.w[st] = wv::ballot(ok);
+        suspect[st] = wv::ballot(sus);
+    }
+    // 5. suspects (a true repetition, or a signature collision): build the position the move gives - captured groups from the
+    //    labels by wave-wide ballots - and compare it with the ancestors of equal signature, whole bit sets from the ring in HBM.
+    //    Wave-uniform and rare (a ko or a retaken position).
+    for (int st = 0; st < WS; ++st)
+        for (uint64_t m = suspect[st]; m; m &= m - 1) {
+            const int bitpos = wv::ctz64(m), a = st * 64 + bitpos;
+            const int row = a / G::COLS, col = a % G::COLS;
+            BB cap = BB::zero();
+            for (int d = 0; d < 4; ++d) {
+                const bool valid = d == 0 ? row > 0 : d == 1 ? col > 0 : d == 2 ? row < G::ROWS - 1 : col < G::COLS - 1;
+                if (!valid) continue;
+                const int nb = d == 0 ? a - G::COLS : d == 1 ? a - 1 : d == 2 ? a + G::COLS : a + 1;
+                if (!opp.test(nb)) continue;
+                const uint32_t g = lds->xu[nb];
+                if (lds->xl[g] != 1u) continue;
+                for (int s2 = 0; s2 < WS; ++s2) cap.w[s2] |= wv::ballot(colr[s2] == 2 && lab[s2] == g);
             }
             const BB nown = own | BB::bit(a), nopp = opp & ~cap;
             const BB np0 = c.player ? nopp : nown, np1 = c.player ? nown : nopp;
-            bool repeat = false;
             const uint64_t sg = pos_sig<G::WORDS>(np0, np1);
+            bool repeat = false;
             for (int i = 0; i < n_hist; ++i)
-                if (lds->hsig[i] == sg) repeat |= (lds->hist[i][0] == np0) && (lds->hist[i][1] == np1);
-            ok = has_libs && !repeat;
+                if (lds->hsig[i] == sg) repeat |= (ring[2 * i] == np0) && (ring[2 * i + 1] == np1);
+            if (repeat) legal.w[st] &= ~(1ull << bitpos);
         }
-        const uint64_t m = wv::ballot(ok);
-        legal.w[st] = m;
-    }
     return legal;
 }
 
@@ -372,9 +433,10 @@ template <class G>
 SPRL_DEV void make_child(GameW& g, WaveLdsW<G>* lds, const PosW<G::WORDS>& parent, int action, int at,
                          PosW<G::WORDS>& cs) {
     G::apply(parent, action, cs);
-    if (wv::lane() == 0) hist_put<G>(lds, at, cs.p0, cs.p1);
-    wv::sync();
-    if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, at + 1, g.legal_form);
+    Bits<G::WORDS>* ring = (Bits<G::WORDS>*)g.ring;
+    if (wv::lane() == 0) hist_put<G>(lds, ring, at, cs.p0, cs.p1);
+    wv::wave_fence();                          // the ring entry is read by other lanes (suspect verification, leaf history)
+    if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, ring, at + 1, g.legal_form);
 }
 
 // Dirichlet root noise (UCTNode.hpp:330-347, utils/random.cpp:61-74)
@@ -562,8 +624,7 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
         g.rootN += 1.0f;
         g.rootW -= 1.0f;
         int depth = 0;
-        NodeHdrW<G::WORDS> h = load_hdr<G>(node_at<G>(g.abase, cur));
-        if (l == 0) hist_put<G>(lds, g.ply, h.p0, h.p1);
+        NodeHdrW<G::WORDS> h = load_hdr<G>(node_at<G>(g.abase, cur));       // (its position is entry g.ply of the line already)
         while (h.exp_epoch == g.epoch && !(h.flags & F_TERMINAL)) {
             uint8_t* np = node_at<G>(g.abase, cur);
             float n[WS], w[WS], score[WS];
@@ -652,7 +713,7 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
                 break;
             }
             h = load_hdr<G>(node_at<G>(g.abase, cur));
-            if (l == 0) hist_put<G>(lds, g.ply + depth, h.p0, h.p1);
+            if (l == 0) hist_put<G>(lds, (Bits<G::WORDS>*)g.ring, g.ply + depth, h.p0, h.p1);
         }
         if (h.flags & F_TERMINAL) {
             const float value = h.winner < 0 ? 0.0f : (h.winner == (int8_t)h.player ? 1.0f : -1.0f);
@@ -674,9 +735,11 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
             for (int j = l; j < depth; j += 64) path[j] = lds->path[j];
             const int last = g.ply + depth;
             const int size = last + 1 < G::HIST ? last + 1 : G::HIST;
+            wv::wave_fence();                  // lane 0 wrote the line's positions, lanes 0..7 read them
             if (l < size) {
-                lds->leaf_hist[q][l][0] = lds->hist[last - l][0];
-                lds->leaf_hist[q][l][1] = lds->hist[last - l][1];
+                const Bits<G::WORDS>* ring = (const Bits<G::WORDS>*)g.ring;
+                lds->leaf_hist[q][l][0] = ring[2 * (last - l)];
+                lds->leaf_hist[q][l][1] = ring[2 * (last - l) + 1];
             }
             if (l == 0) lds->leaf_size[q] = (uint32_t)size;
         }
@@ -786,10 +849,8 @@ SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>*
     g.traversals = 0;
     g.n_leaves = 0;
     g.d_created++;
-    if (wv::lane() == 0) hist_put<G>(lds, 0, s.p0, s.p1);
-    Bits<G::WORDS>* gh = (Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
-    gh[0] = s.p0;
-    gh[1] = s.p1;
+    if (wv::lane() == 0) hist_put<G>(lds, (Bits<G::WORDS>*)g.ring, 0, s.p0, s.p1);
+    wv::wave_fence();
 }
 
 // SelfPlay.hpp:110-148
@@ -910,10 +971,8 @@ SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* l
     g.ply += 1;
     {
         const NodeHdrW<G::WORDS> nh = load_hdr<G>(node_at<G>(g.abase, c));
-        if (l == 0) hist_put<G>(lds, g.ply, nh.p0, nh.p1);
-        Bits<G::WORDS>* gh = (Bits<G::WORDS>*)P.hist_boards + ((size_t)slot * G::HIST_CAP + (size_t)g.ply) * 2;
-        gh[0] = nh.p0;
-        gh[1] = nh.p1;
+        if (l == 0) hist_put<G>(lds, (Bits<G::WORDS>*)g.ring, g.ply, nh.p0, nh.p1);      // the real game's line grows by one
+        wv::wave_fence();
     }
     g.epoch += 1;
     g.traversals = 0;
@@ -948,10 +1007,11 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
     g.d_created = g.d_compactions = g.d_games = g.d_plies = g.d_recycled = 0;
     g.legal_form = P.go_legal_form;
     g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * G::NODE_BYTES;
+    g.ring = (void*)((Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2);
     wv::sync();
-    if (g.status == ST_ACTIVE) {
-        const Bits<G::WORDS>* gh = (const Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2;
-        for (int i = wv::lane(); i <= g.ply; i += 64) hist_put<G>(lds, i, gh[2 * i], gh[2 * i + 1]);
+    if (g.status == ST_ACTIVE) {               // the signatures of the real game's positions, from the ring
+        const Bits<G::WORDS>* gh = (const Bits<G::WORDS>*)g.ring;
+        for (int i = wv::lane(); i <= g.ply; i += 64) lds->hsig[i] = pos_sig<G::WORDS>(gh[2 * i], gh[2 * i + 1]);
         wv::sync();
     }
     if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);

@@ -30,6 +30,15 @@ extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float*
 extern "C" int sprl_wino_weight_layout(void);
 extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                      float* y, int batch, int H, int W, int relu, void* stream);
+extern "C" int sprl_wino_conv64_nchw_tiled(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                           float* y, int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_wino_nchw_tile(int H, int W);
+extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                          long long batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
+                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* logits,
+                              float* value, int batch, int H, int W, int PC, int VC, int A, int HID, const unsigned* batch_dev,
+                              void* stream);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
@@ -54,7 +63,8 @@ namespace {
 struct NativeNet {
     bool ok = false;
     at::Tensor stem_w, stem_scale, stem_shift;
-    struct Block { at::Tensor w1, s1, t1, w2, s2, t2, u1, u2; };   // u*: Winograd-domain weights (cnn_wino.hip)
+    struct Block { at::Tensor w1, s1, t1, w2, s2, t2, u1, u2, u1t3, u2t3; };   // u*: Winograd-domain weights (cnn_wino.hip);
+                                                                               // u*t3: for the F(3x3,3x3) tiling, built on first use
     bool wino = false;              // every trunk convolution is 64 -> 64: the hand-written Winograd/MFMA kernel applies
     std::vector<Block> blocks;
     at::Tensor pconv_w, pconv_b, pfc_w, pfc_b, vconv_w, vconv_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b;
@@ -96,6 +106,8 @@ struct Model {
     NativeNet native;
     ConvProfile prof;
     at::Tensor act[3], maps;     // activation buffers of the hand-written path, kept across calls (no allocator traffic, any stream)
+    at::Tensor nact[3];          // the same for boards wider than 8 (NCHW with the slack sprl_wino_conv64_nchw needs)
+    int64_t nact_boards = 0, nact_hw = 0;
 };
 
 // scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta  (BatchNorm2d eval, eps = 1e-5)
@@ -113,6 +125,26 @@ bool fold_bn(const std::map<std::string, at::Tensor>& t, const std::string& conv
 
 // U = G g G^T for F(4x4, 3x3), computed in double and stored in the lane order of the kernel's A operand:
 // U2[p = xi * 6 + nu][s][kb][lane] with output channel k = 16 kb + lane % 16, input channel = slot lane / 16 of group s.
+// F(3x3, 3x3) (interpolation points 0, 1, -1, 2, inf; the kernel's B^T and A^T are in cnn_wino.hip): U = G g G^T is 5x5, stored
+// as U4[p / 4][s][kb][lane][p % 4] with 7 quads (positions 25..27 are zero and never multiplied).
+void wino_transform_f3(const float* g, float* up) {
+    static const double G[5][3] = { { 1.0 / 2, 0, 0 }, { 1.0 / 2, 1.0 / 2, 1.0 / 2 }, { 1.0 / 6, -1.0 / 6, 1.0 / 6 }, { 1.0 / 6, 1.0 / 3, 2.0 / 3 }, { 0, 0, 1 } };
+    for (size_t i = 0; i < (size_t)7 * 16 * 4 * 64 * 4; ++i) up[i] = 0.0f;
+    for (int k = 0; k < 64; ++k)
+        for (int c = 0; c < 64; ++c) {
+            const float* gk = g + ((size_t)k * 64 + c) * 9;
+            double t[5][3];
+            for (int a = 0; a < 5; ++a)
+                for (int j = 0; j < 3; ++j) t[a][j] = G[a][0] * gk[j] + G[a][1] * gk[3 + j] + G[a][2] * gk[6 + j];
+            for (int a = 0; a < 5; ++a)
+                for (int b = 0; b < 5; ++b) {
+                    const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+                    const int p = a * 5 + b, s = 4 * (c >> 4) + (c & 3), kb = k >> 4, lane = ((c >> 2) & 3) * 16 + (k & 15);
+                    up[((((size_t)(p >> 2) * 16 + s) * 4 + kb) * 64 + lane) * 4 + (p & 3)] = (float)v;
+                }
+        }
+}
+
 void wino_transform(const float* g, float* up) {
     const bool packed4 = sprl_wino_weight_layout() == 2;       // U4[p / 4][s][kb][lane][p % 4] instead of U2[p][s][kb][lane]
     static const double G[6][3] = { { 1.0 / 4, 0, 0 },         { -1.0 / 6, -1.0 / 6, -1.0 / 6 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
@@ -134,10 +166,11 @@ void wino_transform(const float* g, float* up) {
         }
 }
 
-at::Tensor wino_weights(const at::Tensor& w_dev) {
+at::Tensor wino_weights(const at::Tensor& w_dev, int tile = 4) {
     at::Tensor w = w_dev.to(at::kCPU, at::kFloat).contiguous();
-    at::Tensor u = at::empty({ 36 * 64 * 64 }, at::TensorOptions().dtype(at::kFloat));
-    wino_transform(w.data_ptr<float>(), u.data_ptr<float>());
+    at::Tensor u = at::empty({ (tile == 3 ? 28 : 36) * 64 * 64 }, at::TensorOptions().dtype(at::kFloat));
+    if (tile == 3) wino_transform_f3(w.data_ptr<float>(), u.data_ptr<float>());
+    else wino_transform(w.data_ptr<float>(), u.data_ptr<float>());
     return u.to(w_dev.device());
 }
 
@@ -283,6 +316,69 @@ at::Tensor nchw_act(int64_t B, int H, int W, const at::TensorOptions& opts) {
     return at::empty({ n + 12 }, opts).narrow(0, 4, n).view({ B, 64, H, W });
 }
 
+// Boards wider than 8 (Go 9x9, 19x19; any H x W up to 64) with a 64-channel trunk, END TO END in hand-written kernels and
+// without the host: NCHW stem on the matrix cores -> any-board Winograd/MFMA trunk -> heads + FC tail (cnn_epilogue.hip:
+// tail_nchw_kernel), every kernel taking the board count from device memory when `batch_dev` is given (`cap` is then the
+// capacity the grids and the buffers are sized for).  The activation buffers are kept across calls; logits and values are
+// written in place.  No library call, no allocation, no copy, no synchronisation per forward (the earlier
+// wide-board path needed the batch size on the host for three rocBLAS GEMMs and allocated / copied per round).
+// Returns false when this network / board is not covered (the caller falls back to the library path).
+bool nchw_covered(const NativeNet& n, int P, int H, int W, int actions) {
+    const int HID = (int)n.vfc1_w.size(1);
+    return n.wino && (P == 3 || P == 17) && H >= 1 && W >= 1 && H <= 64 && W <= 64 && n.pc == 2 && n.vc == 1 &&
+           n.pfc_w.size(0) == (int64_t)2 * H * W && n.pfc_w.size(1) == actions && n.vfc1_w.size(0) == (int64_t)H * W && HID <= 256 &&
+           n.vfc2_w.numel() == HID && (size_t)(3 * 64 + 3 + (3 * H * W > 512 ? 8 : 16) * (3 * H * W + HID)) * 4 <= 64 * 1024 &&
+           !getenv("SPRL_TORCH_NO_NCHW_NATIVE");
+}
+
+bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W, ConvProfile* prof, float* logits_out,
+                  float* value_out, const unsigned* batch_dev, void* stream, const at::TensorOptions& opts) {
+    const int tile = sprl_wino_nchw_tile(H, W);
+    if (tile == 3 && !mdl->native.blocks.empty() && !mdl->native.blocks[0].u1t3.defined()) {     // first 9x9-class board on this model
+        for (auto& b : mdl->native.blocks) {
+            b.u1t3 = wino_weights(b.w1, 3);
+            b.u2t3 = wino_weights(b.w2, 3);
+        }
+        (void)hipDeviceSynchronize();
+    }
+    const NativeNet& n = mdl->native;
+    const int A = (int)n.pfc_w.size(1), HID = (int)n.vfc1_w.size(1);
+    if ((long long)cap * 64 * H * W * 4 >= 0x7fffff00LL || (long long)cap * H * W * P * 4 >= 0x40000000LL) return false;
+    if (!mdl->nact[0].defined() || mdl->nact_boards < cap || mdl->nact_hw != (int64_t)H * W) {
+        for (auto& t : mdl->nact) t = nchw_act(cap, H, W, opts);
+        mdl->nact_boards = cap;
+        mdl->nact_hw = (int64_t)H * W;
+        (void)hipDeviceSynchronize();            // the buffers may be used on another stream than the one that allocated them
+    }
+    float *x = mdl->nact[0].data_ptr<float>(), *ya = mdl->nact[1].data_ptr<float>(), *za = mdl->nact[2].data_ptr<float>();
+    if (sprl_stem_conv3x3_nchw_dev(planes, n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(), n.stem_shift.data_ptr<float>(), x,
+                                   cap, P, H, W, batch_dev, stream) != 0)
+        return false;
+    auto conv = [&](const float* src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res, float* dst) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
+        if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
+        const int rc = sprl_wino_conv64_nchw_tiled(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1,
+                                                   tile, batch_dev, stream);
+        if (timed) {
+            (void)hipEventRecord(e1, (hipStream_t)stream);
+            prof->ev.push_back(e0);
+            prof->ev.push_back(e1);
+            prof->launches++;
+            prof->boards += cap;
+            if (prof->ev.size() >= 8192) prof->resolve();
+        }
+        return rc == 0;
+    };
+    for (const auto& b : n.blocks) {
+        if (!conv(x, tile == 3 ? b.u1t3 : b.u1, b.s1, b.t1, nullptr, ya) || !conv(ya, tile == 3 ? b.u2t3 : b.u2, b.s2, b.t2, x, za)) return false;
+        std::swap(x, za);
+    }
+    return sprl_tail_nchw(x, n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(),
+                          n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(), n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(),
+                          logits_out, value_out, cap, H, W, n.pc, n.vc, A, HID, batch_dev, stream) == 0;
+}
+
 bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
                     float* logits_out, float* value_out, bool* wrote_outputs, void* stream = nullptr) {
     const NativeNet& n = mdl->native;
@@ -292,6 +388,10 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
     if (wino) {
         if (!forward_wino(mdl, in, p, v, prof, logits_out, value_out, wrote_outputs, nullptr, stream)) return false;
         if (*wrote_outputs) return true;
+    } else if (logits_out && value_out && in.is_contiguous() && nchw_covered(n, P0, H0, W0, (int)n.pfc_w.size(1)) &&
+               forward_nchw(mdl, in.data_ptr<float>(), (int)in.size(0), P0, H0, W0, prof, logits_out, value_out, nullptr, stream, in.options())) {
+        *wrote_outputs = true;                   // the whole forward in our kernels, results already in the caller's buffers
+        return true;
     } else {
         at::Tensor x;
         if ((P0 == 3 || P0 == 17) && n.stem_w.size(0) == 64 && in.is_contiguous() && !getenv("SPRL_TORCH_NO_NCHW_STEM")) {
@@ -506,6 +606,8 @@ static int forward_common(void* handle, const float* planes, int batch, int npla
 
 // host -> host: conv weight [64][64][3][3] to the Winograd-domain layout sprl_wino_conv64 takes (36*64*64 floats)
 void sprl_wino_transform_weights(const float* w, float* u) { wino_transform(w, u); }
+// the same for the F(3x3,3x3) tiling of the any-board kernel (28*64*64 floats)
+void sprl_wino_transform_weights_f3(const float* w, float* u) { wino_transform_f3(w, u); }
 
 // profile mode: time every trunk-convolution launch with HIP events; totals since load (ms, launches, boards)
 void sprl_torch_profile_enable(void* handle, int on) { static_cast<Model*>(handle)->prof.on = on != 0; }
@@ -523,17 +625,21 @@ void sprl_torch_profile_read(void* handle, double* conv_ms, int64_t* launches, i
 // The whole forward with the batch size read ON THE DEVICE (`batch_dev`, <= max_batch): nothing here depends on the host
 // knowing how many leaves the round queued, so the engine can enqueue rounds without a synchronisation in between.
 // `stream`: the HIP stream every kernel of the forward goes to (null = the null stream).
-// Only the hand-written path (kind 2 with the fused tail) can do this; returns -2 when it cannot.
+// Only the hand-written paths (kind 2: layout-W kernels up to 8x8, NCHW kernels for wider boards) can do this; returns -2 when
+// the model or the board is not covered.
 int sprl_torch_forward_dev(void* handle, const float* planes, const unsigned* batch_dev, int max_batch, int nplanes, int rows,
                            int cols, float* logits, int actions, float* value, void* stream, char* err, int errlen) {
     try {
         auto* m = static_cast<Model*>(handle);
         const NativeNet& n = m->native;
         if (!(n.ok && n.wino) || m->device < 0 || n.pfc_w.size(1) != actions || getenv("SPRL_TORCH_NO_FUSED_TAIL")) return -2;
-        if (!((nplanes == 3 || nplanes == 17) && ((rows == 8 && cols == 8) || (rows == 6 && cols == 7) || (rows == 7 && cols == 7))))
-            return -2;
         c10::InferenceMode guard;
         auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, (c10::DeviceIndex)m->device);
+        if (!((nplanes == 3 || nplanes == 17) && ((rows == 8 && cols == 8) || (rows == 6 && cols == 7) || (rows == 7 && cols == 7)))) {
+            // boards wider than 8: the NCHW kernels, same contract
+            if (!nchw_covered(n, nplanes, rows, cols, actions)) return -2;
+            return forward_nchw(m, planes, max_batch, nplanes, rows, cols, &m->prof, logits, value, batch_dev, stream, opts) ? 0 : -2;
+        }
         auto in = torch::from_blob(const_cast<float*>(planes), { max_batch, nplanes, rows, cols }, opts);
         at::Tensor p, v;
         bool wrote = false;

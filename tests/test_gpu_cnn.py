@@ -20,6 +20,8 @@ def plug():
     p.sprl_wino_conv64.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
     p.sprl_wino_transform_weights.argtypes = [C.c_void_p, C.c_void_p]
     p.sprl_wino_conv64_nchw.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
+    p.sprl_wino_conv64_nchw_tiled.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
+    p.sprl_wino_transform_weights_f3.argtypes = [C.c_void_p, C.c_void_p]
     return p
 
 
@@ -95,9 +97,12 @@ def test_wino_structured_inputs(plug):
     assert (got - want).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("tile", [4, 3])
 @pytest.mark.parametrize("H,W,B", [(9, 9, 7), (19, 19, 3), (8, 8, 5), (5, 7, 9), (9, 9, 300), (19, 19, 40), (13, 6, 11)])
-def test_wino_conv_general_boards_nchw(plug, H, W, B):
-    """The any-board variant (workgroup = 16 tiles, patches gathered from NCHW) against conv2d in float64."""
+def test_wino_conv_general_boards_nchw(plug, H, W, B, tile):
+    """The any-board variant (workgroup = 16 tiles, patches gathered from NCHW) against conv2d in float64, in both tilings
+    (F(4x4,3x3): 36 positions per 4x4 tile; F(3x3,3x3): 25 positions per 3x3 tile - the 9x9 choice) on every board, with the
+    board count given by the host and read from device memory (capacity-sized grid)."""
     import torch
     torch.manual_seed(H * 1000 + W * 10 + B)
 
@@ -114,9 +119,9 @@ def test_wino_conv_general_boards_nchw(plug, H, W, B):
     scale = torch.rand(64, device="cuda") + 0.5
     shift = torch.randn(64, device="cuda") * 0.3
     res = act()
-    u = np.zeros(36 * 64 * 64, np.float32)
+    u = np.zeros((36 if tile == 4 else 28) * 64 * 64, np.float32)
     wc = np.ascontiguousarray(w.cpu().numpy())          # keep the host copy alive across the call
-    plug.sprl_wino_transform_weights(wc.ctypes.data, u.ctypes.data)
+    (plug.sprl_wino_transform_weights if tile == 4 else plug.sprl_wino_transform_weights_f3)(wc.ctypes.data, u.ctypes.data)
     ud = torch.from_numpy(u).cuda()
     ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
     for use_res, relu in ((True, True), (False, False)):
@@ -124,12 +129,22 @@ def test_wino_conv_general_boards_nchw(plug, H, W, B):
         if relu:
             want = torch.relu(want)
         y = torch.full_like(x, float("nan"))
-        rc = plug.sprl_wino_conv64_nchw(x.data_ptr(), ud.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                        res.data_ptr() if use_res else None, y.data_ptr(), B, H, W, int(relu), None)
+        rc = plug.sprl_wino_conv64_nchw_tiled(x.data_ptr(), ud.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                              res.data_ptr() if use_res else None, y.data_ptr(), B, H, W, int(relu), tile, None, None)
         assert rc == 0
         torch.cuda.synchronize()
         err = (y.double() - want).abs().max().item()
-        assert err < 8e-5, (H, W, B, use_res, relu, err)
+        assert err < 8e-5, (H, W, B, tile, use_res, relu, err)
+        # the count on the device: only the first `live` boards are computed, nothing behind them is written
+        live = max(1, B // 2)
+        cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+        y2 = torch.full_like(x, float("nan"))
+        rc = plug.sprl_wino_conv64_nchw_tiled(x.data_ptr(), ud.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                              res.data_ptr() if use_res else None, y2.data_ptr(), B, H, W, int(relu), tile,
+                                              cnt.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y2[:live], y[:live]) and torch.isnan(y2[live:]).all()
 
 
 @pytest.mark.parametrize("P,H,W,B", [(17, 9, 9, 7), (17, 19, 19, 3), (3, 13, 6, 11), (17, 9, 9, 513), (3, 9, 9, 1)])
