@@ -380,8 +380,15 @@ def main():
         # the dominant kernel by time: the trunk convolution of the CNN (cnn_wino.hip), fp32 MFMA-bound.
         # Algorithmic work per board and launch = the Winograd-domain products the kernel must issue:
         # 4 tiles x 36 positions x 64 x 64 multiply-adds (4x fewer than the direct 3x3 convolution).
-        tiles = ((G["rows"] + 3) // 4) * ((G["cols"] + 3) // 4)
-        flop_per_board = 2 * tiles * 36 * 64 * 64
+        # the tiling the kernel really uses (cnn_wino.hip: sprl_wino_nchw_tile): boards up to 8x8 F(4x4,3x3), wider boards whichever
+        # of F(4x4,3x3) / F(3x3,3x3) needs fewer position-products (9x9: 3x3 tiles of 3x3 cells, 25 positions each)
+        R, Cc = G["rows"], G["cols"]
+        m_tile, npos = 4, 36
+        if (R > 8 or Cc > 8) and ((R + 2) // 3) * ((Cc + 2) // 3) * 25 < ((R + 3) // 4) * ((Cc + 3) // 4) * 36:
+            m_tile, npos = 3, 25
+        tiles = ((R + m_tile - 1) // m_tile) * ((Cc + m_tile - 1) // m_tile)
+        flop_per_board = 2 * tiles * npos * 64 * 64
+        useful_cells = (R * Cc) / (tiles * m_tile * m_tile)     # MFMA work spent on cells of the board (the rest is tile padding)
         fill = (d["nn_evals"] / d["nn_rows"]) if d.get("nn_rows") else 1.0     # host-batched path: rows padded to a bucket are not work
         flop = d["conv_boards"] * min(1.0, fill) * flop_per_board
         conv_time_ms = M["conv_busy"] if (mp > 1 and M["conv_busy"]) else d["conv_ms"]
@@ -406,8 +413,9 @@ def main():
                 "overlap": (M["conv_sum"] / M["conv_busy"]) if M["conv_busy"] else None,
                 "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
                 "boards_per_launch": boards_per_launch,
-                "flop_per_board": flop_per_board,
-                "direct_conv_equivalent_tflops": tf * 4.0, "populations": mp}
+                "flop_per_board": flop_per_board, "tile": f"F({m_tile}x{m_tile},3x3), {tiles} tiles x {npos} positions per board",
+                "useful_cells_fraction": useful_cells, "frac_useful": tf / MFMA_F32_PEAK_TF * useful_cells,
+                "direct_conv_equivalent_tflops": tf * (9.0 * m_tile * m_tile / npos) * useful_cells, "populations": mp}
         return conv, tree
 
     pops = args.populations if args.populations > 0 else (G.get("populations", 1) if args.model == "cnn" else 1)

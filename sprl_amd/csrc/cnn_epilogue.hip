@@ -299,22 +299,23 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
 }
 }  // namespace
 
-// The same tail for ANY board (Go 9x9 / 19x19), trunk output in NCHW: both 1x1 head convolutions + bias + ReLU, the policy FC
-// and the value FC -> ReLU -> FC -> tanh, written straight into the engine's logits / value buffers.  The board count may be
-// on the device (batch_dev), so nothing here needs the host: it replaces the heads kernel + three library GEMMs (+ their
-// at::empty allocations and output copies) of the earlier wide-board path.  A workgroup takes NB boards: their head maps
-// (NB x OC x HW floats) stay in LDS; the FC weights are streamed from global memory ONCE per workgroup - thread = one output
-// column, consecutive threads read consecutive weights of a row (coalesced), the NB map values of a row are LDS broadcasts -
-// and reused for the NB boards in registers.  The tail is 0.3 % of the network's arithmetic; what matters is that it has
-// no host dependency and no extra passes over the 64-channel activation.
+// The same tail for ANY board (Go 9x9 / 19x19), trunk output in NCHW, in two kernels that read the board count from device
+// memory (batch_dev), so nothing here needs the host: they replace the heads kernel + three library GEMMs (+ their at::empty
+// allocations and output copies) of the earlier wide-board path.
+//   tail_heads_value_kernel: both 1x1 head convolutions + bias + ReLU for NB boards (maps in LDS), the policy maps written out
+//       [batch][PC * HW], and the value head FC -> ReLU -> FC -> tanh;
+//   policy_fc_kernel: logits[B][A] = maps[B][PC * HW] x W[PC * HW][A] + b as a (boards / NB) x (A / 128) grid - at 19x19 the
+//       722 x 362 product of one round's ~1 k boards is 370 workgroups of a few microseconds (a single-kernel form with one
+//       workgroup per 8 boards walked the 722-long contraction twice per workgroup and cost 10 % of the forward).  Thread =
+//       one output column x one half of the contraction; consecutive threads read consecutive weights of a row (coalesced, each
+//       weight once per workgroup, reused for NB boards in registers), the map values are LDS broadcasts.
 template <int OC, int NB>
-__global__ void __launch_bounds__(256) tail_nchw_kernel(const float* __restrict__ x, const float* __restrict__ hw,
-                                                        const float* __restrict__ hb, const float* __restrict__ pfc_w,
-                                                        const float* __restrict__ pfc_b, const float* __restrict__ vfc1_w,
-                                                        const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
-                                                        const float* __restrict__ vfc2_b, float* __restrict__ logits,
-                                                        float* __restrict__ value, int batch, int HW, int PC, int A, int HID,
-                                                        const unsigned* __restrict__ batch_dev) {
+__global__ void __launch_bounds__(256) tail_heads_value_kernel(const float* __restrict__ x, const float* __restrict__ hw,
+                                                               const float* __restrict__ hb, const float* __restrict__ vfc1_w,
+                                                               const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
+                                                               const float* __restrict__ vfc2_b, float* __restrict__ pmaps,
+                                                               float* __restrict__ value, int batch, int HW, int PC, int HID,
+                                                               const unsigned* __restrict__ batch_dev) {
     if (batch_dev) {
         const int real = (int)*batch_dev;
         batch = real < batch ? real : batch;
@@ -328,8 +329,9 @@ __global__ void __launch_bounds__(256) tail_nchw_kernel(const float* __restrict_
     const int tid = (int)threadIdx.x;
     const int nb = batch - n0 < NB ? batch - n0 : NB;
     for (int i = tid; i < OC * 64 + OC; i += 256) s_hw[i] = i < OC * 64 ? hw[i] : hb[i - OC * 64];
+    for (int i = tid; i < NB * OC * HW; i += 256) s_maps[i] = 0.0f;     // boards past the batch contribute zeros below
     __syncthreads();
-    // stage 1: thread = (board, cell); consecutive lanes read consecutive cells of one channel plane
+    // heads: thread = (board, cell); consecutive lanes read consecutive cells of one channel plane
     for (int e = tid; e < nb * HW; e += 256) {
         const int b = e / HW, cell = e - b * HW;
         const float* xp = x + ((size_t)(n0 + b) * 64) * HW + cell;
@@ -349,44 +351,97 @@ __global__ void __launch_bounds__(256) tail_nchw_kernel(const float* __restrict_
         }
     }
     __syncthreads();
-    // stage 2a: policy FC, thread = output column a
     const int PIN = PC * HW, VIN = (OC - PC) * HW;
-    for (int a = tid; a < A; a += 256) {
+    for (int e = tid; e < nb * PIN; e += 256) {
+        const int b = e / PIN, q = e - b * PIN;
+        pmaps[(size_t)(n0 + b) * PIN + q] = s_maps[b * (OC * HW) + q];
+    }
+    // value head: FC1 + ReLU, thread = (hidden unit j, quarter of the contraction); then FC2 + tanh per board
+    const int j = tid & 63, part = tid >> 6;           // HID <= 64 (checked by the host)
+    {
         float acc[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
-        for (int q = 0; q < PIN; ++q) {
-            const float w = pfc_w[(size_t)q * A + a];
+        const int q0 = (VIN * part) / 4, q1 = (VIN * (part + 1)) / 4;
+        if (j < HID)
+            for (int q = q0; q < q1; ++q) {
+                const float w = vfc1_w[(size_t)q * HID + j];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] += s_maps[b * (OC * HW) + q] * w;
+                for (int b = 0; b < NB; ++b) acc[b] += s_maps[b * (OC * HW) + PIN + q] * w;
+            }
+        // the four partial sums of a hidden unit are added in a fixed order through LDS
+        float* const s_part = s_hid + NB * 64;         // [4][NB][64]
+#pragma unroll
+        for (int b = 0; b < NB; ++b) s_part[(part * NB + b) * 64 + j] = acc[b];
+        __syncthreads();
+        if (part == 0 && j < HID) {
+            const float bias = vfc1_b[j], w2 = vfc2_w[j];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float h = ((s_part[(0 * NB + b) * 64 + j] + s_part[(1 * NB + b) * 64 + j]) + s_part[(2 * NB + b) * 64 + j]) +
+                                s_part[(3 * NB + b) * 64 + j] + bias;
+                s_hid[b * 64 + j] = (h > 0.0f ? h : 0.0f) * w2;
+            }
         }
+        __syncthreads();
+    }
+    if (tid < nb) {
+        float sum = vfc2_b[0];
+        for (int jj = 0; jj < HID; ++jj) sum += s_hid[tid * 64 + jj];
+        value[n0 + tid] = tanhf(sum);
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256) policy_fc_kernel(const float* __restrict__ pmaps, const float* __restrict__ pfc_w,
+                                                        const float* __restrict__ pfc_b, float* __restrict__ logits, int batch,
+                                                        int PIN, int A, const unsigned* __restrict__ batch_dev) {
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+    }
+    const int n0 = (int)blockIdx.x * NB;
+    if (n0 >= batch) return;
+    extern __shared__ float fsh[];
+    float* const s_in = fsh;                           // [NB][PIN]
+    float* const s_red = fsh + NB * PIN;               // [NB][128]: the second half's partial sums
+    const int tid = (int)threadIdx.x;
+    const int nb = batch - n0 < NB ? batch - n0 : NB;
+    for (int i = tid; i < NB * PIN; i += 256) s_in[i] = i < nb * PIN ? pmaps[(size_t)n0 * PIN + i] : 0.0f;
+    __syncthreads();
+    const int al = tid & 127, kh = tid >> 7;
+    const int a = (int)blockIdx.y * 128 + al;
+    const int q0 = kh ? PIN / 2 : 0, q1 = kh ? PIN : PIN / 2;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
+    if (a < A) {
+        const float* wp = pfc_w + a;
+        int q = q0;
+        for (; q + 4 <= q1; q += 4) {                  // four weights in flight per thread
+            const float w0 = wp[(size_t)q * A], w1 = wp[(size_t)(q + 1) * A], w2 = wp[(size_t)(q + 2) * A], w3 = wp[(size_t)(q + 3) * A];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float* m = s_in + b * PIN + q;
+                acc[b] = acc[b] + m[0] * w0 + m[1] * w1 + m[2] * w2 + m[3] * w3;
+            }
+        }
+        for (; q < q1; ++q) {
+            const float w0 = wp[(size_t)q * A];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] += s_in[b * PIN + q] * w0;
+        }
+    }
+    if (kh) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) s_red[b * 128 + al] = acc[b];
+    }
+    __syncthreads();
+    if (!kh && a < A) {
         const float bias = pfc_b[a];
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-            if (b < nb) logits[(size_t)(n0 + b) * A + a] = acc[b] + bias;
-    }
-    // stage 2b: value FC1 + ReLU, thread = hidden unit j; then FC2 + tanh per board
-    for (int j = tid; j < HID; j += 256) {
-        float acc[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
-        for (int q = 0; q < VIN; ++q) {
-            const float w = vfc1_w[(size_t)q * HID + j];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] += s_maps[b * (OC * HW) + PIN + q] * w;
-        }
-        const float bias = vfc1_b[j], w2 = vfc2_w[j];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float h = acc[b] + bias;
-            s_hid[b * HID + j] = (h > 0.0f ? h : 0.0f) * w2;
-        }
-    }
-    __syncthreads();
-    if (tid < nb) {
-        float sum = vfc2_b[0];
-        for (int j = 0; j < HID; ++j) sum += s_hid[tid * HID + j];
-        value[n0 + tid] = tanhf(sum);
+            if (b < nb) logits[(size_t)(n0 + b) * A + a] = (acc[b] + s_red[b * 128 + al]) + bias;
     }
 }
 
@@ -643,26 +698,31 @@ extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* h
 }
 
 // x: trunk output NCHW [batch][64][H*W]; hw/hb: [PC + VC][64] / [PC + VC] head convolutions (policy rows first); pfc_w: [PC*H*W][A]
-// (transposed Linear weight), vfc1_w: [VC*H*W][HID], vfc2_w: [HID]; logits: [batch][A], value: [batch]; batch_dev: optional
-// device pointer to the real board count (<= batch).  -1: shape not covered (the caller falls back to the library GEMMs).
+// (transposed Linear weight), vfc1_w: [VC*H*W][HID], vfc2_w: [HID]; pmaps: scratch [batch][PC*H*W]; logits: [batch][A], value:
+// [batch]; batch_dev: optional device pointer to the real board count (<= batch).  -1: shape not covered (the caller falls back
+// to the library GEMMs).
 extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
-                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* logits,
-                              float* value, int batch, int H, int W, int PC, int VC, int A, int HID, const unsigned* batch_dev,
-                              void* stream) {
+                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* pmaps,
+                              float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                              const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
-    const int OC = PC + VC, HW = H * W;
-    if (OC != 3 || PC != 2 || HID > 256) return -1;
+    const int OC = PC + VC, HW = H * W, PIN = PC * HW;
+    if (OC != 3 || PC != 2 || HID > 64) return -1;
     const bool big = OC * HW > 512;                    // 19x19: 1083 floats of maps per board -> 8 boards per workgroup
     const int NB = big ? 8 : 16;
-    const size_t lds = (size_t)(OC * 64 + OC + NB * OC * HW + NB * HID) * sizeof(float);
-    if (lds > 64 * 1024) return -1;
-    const dim3 grid((unsigned)((batch + NB - 1) / NB)), block(256);
+    const size_t lds_a = (size_t)(OC * 64 + OC + NB * OC * HW + NB * 64 + 4 * NB * 64) * sizeof(float);
+    const size_t lds_b = (size_t)(NB * PIN + NB * 128) * sizeof(float);
+    if (lds_a > 64 * 1024 || lds_b > 64 * 1024) return -1;
+    const dim3 grid_a((unsigned)((batch + NB - 1) / NB)), grid_b((unsigned)((batch + NB - 1) / NB), (unsigned)((A + 127) / 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (big)
-        hipLaunchKernelGGL((tail_nchw_kernel<3, 8>), grid, block, lds, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
-                           value, batch, HW, PC, A, HID, batch_dev);
-    else
-        hipLaunchKernelGGL((tail_nchw_kernel<3, 16>), grid, block, lds, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
-                           value, batch, HW, PC, A, HID, batch_dev);
+    if (big) {
+        hipLaunchKernelGGL((tail_heads_value_kernel<3, 8>), grid_a, block, lds_a, st, x, hw, hb, vfc1_w, vfc1_b, vfc2_w, vfc2_b, pmaps, value,
+                           batch, HW, PC, HID, batch_dev);
+        hipLaunchKernelGGL((policy_fc_kernel<8>), grid_b, block, lds_b, st, pmaps, pfc_w, pfc_b, logits, batch, PIN, A, batch_dev);
+    } else {
+        hipLaunchKernelGGL((tail_heads_value_kernel<3, 16>), grid_a, block, lds_a, st, x, hw, hb, vfc1_w, vfc1_b, vfc2_w, vfc2_b, pmaps, value,
+                           batch, HW, PC, HID, batch_dev);
+        hipLaunchKernelGGL((policy_fc_kernel<16>), grid_b, block, lds_b, st, pmaps, pfc_w, pfc_b, logits, batch, PIN, A, batch_dev);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

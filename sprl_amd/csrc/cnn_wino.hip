@@ -86,7 +86,7 @@ constexpr int IN_BUF2 = 8 * CS2;
 constexpr int V_G2 = 36 * 64;            // V of one group: [p][c_sub][16 tiles]
 constexpr int LDS_FLOATS2 = 2 * IN_BUF2 + 4 * V_G2;      // 65.6 KB
 
-template <int H, int W, int HEADS = 0>
+template <int H, int W, int HEADS = 0, int RES = 1>
 __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ res, float* __restrict__ y, int batch,
@@ -134,9 +134,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // the store; on gfx950 that corrupted dword 1 of lanes 12-15 of every 16 (found with tools/wino_lab.hip).
     const int ovoff = ((n0 + (tl >> 2)) * 4096 + kb * 1024 + c_sub * 16 + tile * 4) * 4;
 
-    f4 acc[36];
-#pragma unroll
-    for (int q = 0; q < 36; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    f4 acc[36];                                       // first written by the first K step (C operand = 0): no zero fill
     f4 pre[2];                                        // the activation chunk in flight
     auto gload_to = [&](int chunk, f4 (&dst)[2]) {
 #pragma unroll
@@ -149,6 +147,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = src[it][j];
     };
+    // B^T rows written as fused multiply-adds (two instructions for 4 a - 5 b + c, one for c - 4 b): the kernel is bound by the
+    // number of VALU instructions a SIMD retires beside its MFMAs (round 3), so every instruction counts
     auto produce = [&](int c) {
         const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
         float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
@@ -157,8 +157,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
-                const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
-                wr[0][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                const float p = __builtin_fmaf(-4.0f, e2, e4), q = __builtin_fmaf(-4.0f, e1, e3);
+                wr[0][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
                 wr[1][j] = p + q;
                 wr[2][j] = p - q;
             }
@@ -166,22 +166,22 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
-                const float p = e3 - e1, q = 2.0f * (e2 - e0);
-                wr[0][j] = p + q;
-                wr[1][j] = p - q;
-                wr[2][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                const float p = e3 - e1, d = e2 - e0;
+                wr[0][j] = __builtin_fmaf(2.0f, d, p);
+                wr[1][j] = __builtin_fmaf(-2.0f, d, p);
+                wr[2][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
             }
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
-            const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
-            vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
+            const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3), p2 = w4 - w2, d2 = w3 - w1;
+            vd[(r * 6 + 0) * 64] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
             vd[(r * 6 + 1) * 64] = p + q;
             vd[(r * 6 + 2) * 64] = p - q;
-            vd[(r * 6 + 3) * 64] = p2 + q2;
-            vd[(r * 6 + 4) * 64] = p2 - q2;
-            vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
+            vd[(r * 6 + 3) * 64] = __builtin_fmaf(2.0f, d2, p2);
+            vd[(r * 6 + 4) * 64] = __builtin_fmaf(-2.0f, d2, p2);
+            vd[(r * 6 + 5) * 64] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
         }
     };
     // A operand: U4[p / 4][s][kb][lane][p % 4] (16-byte loads, four transform positions each); 36-register ring
@@ -189,8 +189,10 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     auto aload = [&](int s, int q4) {
         a[q4] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, ulane, (q4 * 16 + s) * 4096 + kb * 1024, 0));
     };
-    // one K step = one group of 4 input channels: 36 MFMAs; `chunk` >= 0: request that activation chunk behind the filters
-    auto kstep = [&](const float* vg, int s, int chunk) {
+    // one K step = one group of 4 input channels: 36 MFMAs; `chunk` >= 0: request that activation chunk behind the filters.
+    // FIRST: the accumulators start from the MFMA's constant-zero C operand (no 144-instruction zero fill per wave)
+    auto kstep = [&](const float* vg, int s, int chunk, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         __builtin_amdgcn_sched_barrier(0);
         if (chunk >= 0) gload_to(chunk, pre);
 #pragma unroll
@@ -198,19 +200,23 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int p = q4 * 4 + e;
-                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], vg[p * 64 + lane], acc[p], 0, 0, 0);
+                if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], vg[p * 64 + lane], (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
+                else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], vg[p * 64 + lane], acc[p], 0, 0, 0);
             }
             if (s + 1 < 16) aload(s + 1, q4);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // The phase loop is rotated by one K step: K step 0 runs before the loop (it is the one that defines the accumulators), an
+    // iteration is then {chunk c+2 to LDS, K step 2c+1, V(c+1), barrier, K step 2c+2}.  Same order of operations as
+    // {K step 2c, ..., K step 2c+1, V(c+1), barrier} per phase, only the loop boundary sits elsewhere.
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * V_G2;
-        kstep(vs, 2 * c, -1);
         if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
-        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1);
+        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{});
         if (c + 1 < 8) produce(c + 1);
         __syncthreads();
+        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G2, 2 * c + 2, -1, std::false_type{});
     };
 
     f4 rres[4][4];
@@ -234,11 +240,15 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     __syncthreads();
     produce(0);
     __syncthreads();
+    kstep(v_buf, 0, -1, std::true_type{});
     for (int c = 0; c < 8; ++c) phase(c);             // stays a rolled loop: peeled or fully unrolled forms measured 5 % slower
 
     // ---- inverse transform in registers + epilogue ----
-    rload(0);
-    rload(1);
+    if (RES) {
+        rload(0);
+        rload(1);
+    }
+    const float relu_floor = relu ? 0.0f : -__builtin_inff();      // ReLU as one v_max against a scalar (no select per element)
     constexpr int OC = 3;                              // HEADS: 2 policy + 1 value head channels
     float hp[HEADS ? OC : 1][4][4];                    // HEADS: this lane's share of the 1x1 head convolutions (its 4 channels)
     if (HEADS) {
@@ -267,11 +277,11 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f4 v;
-            const f4 rv = rres[r][i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = o[i][j] * sc + sh + rv[j];
-                if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                v[j] = __builtin_fmaf(o[i][j], sc, sh);
+                if (RES) v[j] += rres[r][i][j];
+                v[j] = __builtin_fmaxf(v[j], relu_floor);
                 if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;       // cells off the board stay zero
             }
             if (HEADS) {
@@ -283,7 +293,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * 1024 + i * 256), 0, 2);
             }
         }
-        if (r + 2 < 4) rload(r + 2);
+        if (RES && r + 2 < 4) rload(r + 2);
     }
     if (!HEADS) return;
 
@@ -338,6 +348,15 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------
 constexpr unsigned SLACK_G = 32;                      // bytes that must be readable behind x and res (see the kernel)
 
+// tools/nchw_lab.py builds this file with -DSPRL_WINO_LAB: a run-time mask switches stages of the any-board kernel off so that
+// their cost can be read from the launch time (results are then wrong).  Never defined in the product build.
+#ifdef SPRL_WINO_LAB
+__constant__ int wino_lab_dbg;
+#define LAB_OFF(bit) (wino_lab_dbg & (1 << (bit)))
+#else
+#define LAB_OFF(bit) 0
+#endif
+
 template <int M>
 struct NchwGeom {
     static constexpr int PT = M + 2;                  // patch width
@@ -371,7 +390,7 @@ __device__ __forceinline__ void inverse_transform3(const float (&m)[5][5], float
     }
 }
 
-template <int M, int OCC>
+template <int M, int OCC, int RES>
 __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     const float* __restrict__ res, float* __restrict__ y, int batch,
@@ -402,9 +421,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     const int t_tt = tg < total_tiles ? tg % TPB : 0;
     const int t_row0 = M * (t_tt / TX), t_col0 = M * (t_tt % TX);
 
-    f4 acc[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) acc[q] = (f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    f4 acc[NP];                                       // first written by the first K step (C operand = 0): no zero fill
 
     // chunk = groups 2c, 2c+1: 8 channel slots x 16 tiles x NP patch values.  Loader thread = (tile, slot, half): the patch
     // rows 3 half .. 3 half + 2 of one (channel slot, tile) (M = 3, half 1: rows 3 and 4)
@@ -442,6 +459,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         const int g = 2 * chunk + (ld_slot >> 2);
         const int k = 16 * (g >> 2) + 4 * (ld_slot & 3) + (g & 3);
         const int koff = k * HW * 4;
+        if (LAB_OFF(0)) return;                        // lab: no activation loads
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const f4 a4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_rowoff[i] + koff, 0, 0));
@@ -455,23 +473,26 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         }
     };
     auto lstore = [&](float* buf) {
+        if (LAB_OFF(1)) return;                        // lab: no patch stores to LDS
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
             if (M == 4 || q < 2 * PT || ld_half == 0) buf[ld_lds + q] = ld_colok[q % PT] ? pre[q] : 0.0f;      // columns off the board
     };
-    const int patch0 = (gl * 4 + c_sub) * SS + tl * PS + wa * 3 * PT;
+    // producer half 1 reads from patch row 1 on (M = 4: its rows 3..5 use patch rows 1..5) / sits at patch row 3 (M = 3)
+    const int patch0 = (gl * 4 + c_sub) * SS + tl * PS + wa * (M == 4 ? PT : 3 * PT);
     const int vdst0 = gl * VG + (3 * wa) * PT * 64 + lane;
     auto produce = [&](int c) {
         const float* pp = in_buf + (c & 1) * IN_BUF + patch0;
         float* vd = v_buf + (c & 1) * 2 * VG + vdst0;
+        if (LAB_OFF(2)) return;                        // lab: no input transform
         if (M == 4) {
             float wr[3][6];
             if (wa == 0) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
-                    const float p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
-                    wr[0][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                    const float p = __builtin_fmaf(-4.0f, e2, e4), q = __builtin_fmaf(-4.0f, e1, e3);
+                    wr[0][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
                     wr[1][j] = p + q;
                     wr[2][j] = p - q;
                 }
@@ -479,22 +500,22 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
-                    const float p = e3 - e1, q = 2.0f * (e2 - e0);
-                    wr[0][j] = p + q;
-                    wr[1][j] = p - q;
-                    wr[2][j] = 4.0f * e0 - 5.0f * e2 + e4;
+                    const float p = e3 - e1, d = e2 - e0;
+                    wr[0][j] = __builtin_fmaf(2.0f, d, p);
+                    wr[1][j] = __builtin_fmaf(-2.0f, d, p);
+                    wr[2][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
                 }
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
-                const float p = w4 - 4.0f * w2, q = w3 - 4.0f * w1, p2 = w4 - w2, q2 = 2.0f * (w3 - w1);
-                vd[(r * 6 + 0) * 64] = 4.0f * w0 - 5.0f * w2 + w4;
+                const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3), p2 = w4 - w2, d2 = w3 - w1;
+                vd[(r * 6 + 0) * 64] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
                 vd[(r * 6 + 1) * 64] = p + q;
                 vd[(r * 6 + 2) * 64] = p - q;
-                vd[(r * 6 + 3) * 64] = p2 + q2;
-                vd[(r * 6 + 4) * 64] = p2 - q2;
-                vd[(r * 6 + 5) * 64] = 4.0f * w1 - 5.0f * w3 + w5;
+                vd[(r * 6 + 3) * 64] = __builtin_fmaf(2.0f, d2, p2);
+                vd[(r * 6 + 4) * 64] = __builtin_fmaf(-2.0f, d2, p2);
+                vd[(r * 6 + 5) * 64] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
             }
         } else {
             // F(3x3,3x3): half 0 builds transform rows 0..2 (from patch rows 0..3), half 1 rows 3..4 (from patch rows 1..4, i.e.
@@ -505,16 +526,16 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
                 for (int j = 0; j < 5; ++j) {
                     const float e0 = pp[j], e1 = pp[5 + j], e2 = pp[10 + j], e3 = pp[15 + j];
                     const float t = e3 - e1;                               // B^T rows: [2 -1 -2 1 0], [0 2 1 -1 0], [0 -2 3 -1 0]
-                    wr[0][j] = 2.0f * (e0 - e2) + t;
+                    wr[0][j] = __builtin_fmaf(2.0f, e0 - e2, t);
                     wr[1][j] = (e2 + e1) - t;
-                    wr[2][j] = 3.0f * e2 - 2.0f * e1 - e3;
+                    wr[2][j] = __builtin_fmaf(3.0f, e2, __builtin_fmaf(-2.0f, e1, -e3));
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     const float e1 = pp[j - 10], e2 = pp[j - 5], e3 = pp[j], e4 = pp[5 + j];
                     wr[0][j] = e3 - e1;                                    // [0 -1 0 1 0]
-                    wr[1][j] = 2.0f * (e1 - e3) - e2 + e4;                 // [0 2 -1 -2 1]
+                    wr[1][j] = __builtin_fmaf(2.0f, e1 - e3, e4 - e2);     // [0 2 -1 -2 1]
                     wr[2][j] = 0.0f;
                 }
             }
@@ -524,11 +545,11 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
                 if (r < nr) {
                     const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4];
                     const float t = w3 - w1;
-                    vd[(r * 5 + 0) * 64] = 2.0f * (w0 - w2) + t;
+                    vd[(r * 5 + 0) * 64] = __builtin_fmaf(2.0f, w0 - w2, t);
                     vd[(r * 5 + 1) * 64] = (w2 + w1) - t;
-                    vd[(r * 5 + 2) * 64] = 3.0f * w2 - 2.0f * w1 - w3;
+                    vd[(r * 5 + 2) * 64] = __builtin_fmaf(3.0f, w2, __builtin_fmaf(-2.0f, w1, -w3));
                     vd[(r * 5 + 3) * 64] = t;
-                    vd[(r * 5 + 4) * 64] = 2.0f * (w1 - w3) - w2 + w4;
+                    vd[(r * 5 + 4) * 64] = __builtin_fmaf(2.0f, w1 - w3, w4 - w2);
                 }
             }
         }
@@ -536,26 +557,28 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     const f4* ua = (const f4*)u + kb * 64 + lane;
     f4 a[NQ];
     auto aload = [&](int s, int k) { a[k] = ua[(size_t)k * (16 * 4 * 64) + s * 256]; };
-    auto mma = [&](const float* vg, int k) {
+    // one K step (group of 4 input channels): NP MFMAs; FIRST: the accumulators start from the constant-zero C operand
+    auto kstep = [&](const float* vg, int s, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        if (!FIRST && LAB_OFF(3)) return;              // lab: only the first K step (no MFMA loop)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (k * 4 + q < NP) {
-                const float b = vg[(k * 4 + q) * 64 + lane];
-                acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
+        for (int k = 0; k < NQ; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (k * 4 + q < NP) {
+                    const float b = vg[(k * 4 + q) * 64 + lane];
+                    if (FIRST) acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
+                    else acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
+                }
             }
+            if (s + 1 < 16) aload(s + 1, k);
         }
     };
+    // rotated by one K step like the 8x8 kernel's loop: K step 0 runs before the loop, an iteration is {K step 2c+1, V(c+1),
+    // chunk c+2 to LDS, request chunk c+3, barrier, K step 2c+2}
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * VG;
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-            const int s = 2 * c + g2;
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-                mma(vs + g2 * VG, k);
-                if (s + 1 < 16) aload(s + 1, k);
-            }
-        }
+        kstep(vs + VG, 2 * c + 1, std::false_type{});
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < 8) produce(c + 1);
         if (c + 2 < 8) {
@@ -563,6 +586,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
             if (c + 3 < 8) gload(c + 3);
         }
         __syncthreads();
+        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * VG, 2 * c + 2, std::false_type{});
     };
 
     gload(0);
@@ -575,6 +599,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     __syncthreads();
     produce(0);
     __syncthreads();
+    kstep(v_buf, 0, std::true_type{});
     for (int c = 0; c < 8; ++c) phase(c);
 
     // ---- inverse transform in registers + epilogue, NCHW ----
@@ -584,18 +609,24 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     for (int i = 0; i < M; ++i) o_rowoff[i] = (t_n >= 0 && t_row0 + i < H) ? ((t_n * 64) * HW + (t_row0 + i) * W + t_col0) * 4 : OOB;
 #pragma unroll
     for (int j = 0; j < M; ++j) o_colsel[j] = (t_col0 + j < W) ? 0 : OOB;
+    // The per-lane offsets carry the lane's first channel (16 kb + 4 c_sub); output component r adds r * HW * 4 bytes, which is
+    // wave-uniform and goes into the instructions' SCALAR offset - no vector arithmetic per store (bit 31 keeps marking
+    // "off the board": the hardware adds the scalar offset after the range check's comparison value can no longer wrap).
+    const int koff0 = (16 * kb + 4 * c_sub) * HW * 4;
+#pragma unroll
+    for (int i = 0; i < M; ++i) o_rowoff[i] = o_rowoff[i] < 0 ? OOB : o_rowoff[i] + koff0;
     // residual values of output component r (channel 16 kb + 4 c_sub + r), requested one component ahead of their use
     f4 rres[2][M];
     auto rload = [&](int r, f4 (&dst)[M]) {
-        const int koff = (16 * kb + 4 * c_sub + r) * HW * 4;
 #pragma unroll
-        for (int i = 0; i < M; ++i) dst[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, o_rowoff[i] + koff, 0, 0));
+        for (int i = 0; i < M; ++i) dst[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, o_rowoff[i], r * HW * 4, 0));
     };
-    rload(0, rres[0]);
+    if (RES) rload(0, rres[0]);
+    const float relu_floor = relu ? 0.0f : -__builtin_inff();      // ReLU as one v_max against a scalar (no select per element)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         __builtin_amdgcn_sched_barrier(0);
-        if (r + 1 < 4) rload(r + 1, rres[(r + 1) & 1]);
+        if (RES && r + 1 < 4) rload(r + 1, rres[(r + 1) & 1]);
         float m[PT][PT];
 #pragma unroll
         for (int p = 0; p < NP; ++p) m[p / PT][p % PT] = acc[p][r];
@@ -604,14 +635,15 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         else inverse_transform3(m, o);
         const int k = 16 * kb + 4 * c_sub + r;
         const float sc = scale[k], sh = shift[k];
-        const int koff = k * HW * 4;
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                float v = o[i][j] * sc + sh + rres[r & 1][i][j];
-                if (relu) v = v > 0.0f ? v : 0.0f;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ((o_rowoff[i] + koff) | o_colsel[j]) + j * 4, 0, 0);
+                float v = __builtin_fmaf(o[i][j], sc, sh);
+                if (RES) v += rres[r & 1][i][j];
+                v = __builtin_fmaxf(v, relu_floor);
+                if (LAB_OFF(4) && v != 12345.0f) continue;     // lab: no output stores
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (o_rowoff[i] | o_colsel[j]) + j * 4, r * HW * 4, 0);
             }
     }
 }
@@ -624,15 +656,25 @@ extern "C" int sprl_wino_weight_layout(void) { return 2; }
 namespace {
 template <int HEADS>
 int launch_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y, int batch,
-                  int H, int W, int relu, const unsigned* batch_dev, const HeadArgs& ha, void* stream) {
+                  int H, int W, int relu, const unsigned* batch_dev, const HeadArgs& ha_in, void* stream) {
     if (batch <= 0) return 0;
     if ((long long)batch * 16384LL >= 0xFFFFFFFFLL) return -1;      // byte offsets of the buffer descriptors are 32 bits
+    const HeadArgs& ha = ha_in;
     const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
     hipStream_t st = (hipStream_t)stream;
-    if (H == 8 && W == 8) hipLaunchKernelGGL((wino_conv64_kernel<8, 8, HEADS>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);
-    else if (H == 6 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<6, 7, HEADS>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);
-    else if (H == 7 && W == 7) hipLaunchKernelGGL((wino_conv64_kernel<7, 7, HEADS>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);
+    // RES = 0: the first convolution of a residual block has no residual input - no loads, no adds for it
+#define SPRL_LAUNCH_CONV(HH, WW)                                                                                                        \
+    do {                                                                                                                                \
+        if (HEADS || res)                                                                                                               \
+            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, HEADS, 1>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha); \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);     \
+    } while (0)
+    if (H == 8 && W == 8) SPRL_LAUNCH_CONV(8, 8);
+    else if (H == 6 && W == 7) SPRL_LAUNCH_CONV(6, 7);
+    else if (H == 7 && W == 7) SPRL_LAUNCH_CONV(7, 7);
     else return -1;
+#undef SPRL_LAUNCH_CONV
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 }  // namespace
@@ -683,12 +725,18 @@ extern "C" int sprl_wino_conv64_nchw_tiled(const float* x, const float* u, const
     // F(3x3): 50 KB of LDS per workgroup, so three fit a CU if the kernel is held to 168 registers (11 of them then spill);
     // SPRL_WINO_F3_OCC=2 selects the two-per-CU build without spills (measured: DESIGN.md section 5)
     static const int f3_occ = getenv("SPRL_WINO_F3_OCC") ? atoi(getenv("SPRL_WINO_F3_OCC")) : 3;
-    if (tile == 4)
-        hipLaunchKernelGGL((wino_conv64_nchw_kernel<4, 2>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev);
-    else if (f3_occ == 2)
-        hipLaunchKernelGGL((wino_conv64_nchw_kernel<3, 2>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev);
-    else
-        hipLaunchKernelGGL((wino_conv64_nchw_kernel<3, 3>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev);
+    // RES = 0: the first convolution of a residual block has no residual input - no loads, no adds for it
+#define SPRL_LAUNCH_NCHW(MM, OO)                                                                                                          \
+    do {                                                                                                                                  \
+        if (res)                                                                                                                          \
+            hipLaunchKernelGGL((wino_conv64_nchw_kernel<MM, OO, 1>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev); \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((wino_conv64_nchw_kernel<MM, OO, 0>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev); \
+    } while (0)
+    if (tile == 4) SPRL_LAUNCH_NCHW(4, 2);
+    else if (f3_occ == 2) SPRL_LAUNCH_NCHW(3, 2);
+    else SPRL_LAUNCH_NCHW(3, 3);
+#undef SPRL_LAUNCH_NCHW
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 // F(4x4,3x3) tiling, as before
@@ -700,3 +748,7 @@ extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float
                                      float* y, int batch, int H, int W, int relu, void* stream) {
     return sprl_wino_conv64_nchw_tiled(x, u, scale, shift, res, y, batch, H, W, relu, 4, nullptr, stream);
 }
+
+#ifdef SPRL_WINO_LAB
+extern "C" int sprl_wino_lab_set_dbg(int mask) { return hipMemcpyToSymbol(HIP_SYMBOL(wino_lab_dbg), &mask, sizeof(int)) == hipSuccess ? 0 : -1; }
+#endif

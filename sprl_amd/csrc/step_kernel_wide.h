@@ -167,10 +167,33 @@ SPRL_DEV void reclaim_refill(const EngineParams& P, GameW& g, int slot, WaveLdsW
     }
 }
 
+// A node header is wave-uniform, but it comes from a vector load (the arenas are written by this kernel, so the compiler may
+// not use the scalar cache) and would live in vector registers with every lane repeating the same bit-set arithmetic.  On the
+// boards of up to two words the fields are moved to scalar registers (v_readfirstlane): move generation then runs on the scalar
+// ALU and the kernel needs half the vector registers.  (At six words the three bit sets alone are 36 scalar registers per
+// header and several headers / positions are live at once: they stay where they are.)
 template <class G>
 SPRL_DEV NodeHdrW<G::WORDS> load_hdr(uint8_t* n) {
     NodeHdrW<G::WORDS> h = *hdr_of<G>(n);
     wv::sync();
+    if constexpr (G::WORDS <= 2) {
+        for (int w = 0; w < G::WORDS; ++w) {
+            h.p0.w[w] = wv::uni(h.p0.w[w]);
+            h.p1.w[w] = wv::uni(h.p1.w[w]);
+            h.legal.w[w] = wv::uni(h.legal.w[w]);
+        }
+        h.value = wv::uni(h.value);
+        h.exp_epoch = wv::uni(h.exp_epoch);
+        h.passN = wv::uni(h.passN);
+        h.passW = wv::uni(h.passW);
+        h.passP = wv::uni(h.passP);
+        h.passChild = wv::uni(h.passChild);
+        h.player = (uint8_t)wv::uni((uint32_t)h.player);
+        h.flags = (uint8_t)wv::uni((uint32_t)h.flags);
+        h.winner = (int8_t)wv::uni((int)h.winner);
+        h.action = (uint16_t)wv::uni((uint32_t)h.action);
+        h.depth = (uint16_t)wv::uni((uint32_t)h.depth);
+    }
     return h;
 }
 

@@ -36,9 +36,9 @@ extern "C" int sprl_wino_nchw_tile(int H, int W);
 extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                           long long batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
-                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* logits,
-                              float* value, int batch, int H, int W, int PC, int VC, int A, int HID, const unsigned* batch_dev,
-                              void* stream);
+                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* pmaps,
+                              float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                              const unsigned* batch_dev, void* stream);
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    int batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
@@ -106,7 +106,7 @@ struct Model {
     NativeNet native;
     ConvProfile prof;
     at::Tensor act[3], maps;     // activation buffers of the hand-written path, kept across calls (no allocator traffic, any stream)
-    at::Tensor nact[3];          // the same for boards wider than 8 (NCHW with the slack sprl_wino_conv64_nchw needs)
+    at::Tensor nact[3], npmaps;  // the same for boards wider than 8 (NCHW with the slack sprl_wino_conv64_nchw needs; policy head maps)
     int64_t nact_boards = 0, nact_hw = 0;
 };
 
@@ -326,8 +326,9 @@ at::Tensor nchw_act(int64_t B, int H, int W, const at::TensorOptions& opts) {
 bool nchw_covered(const NativeNet& n, int P, int H, int W, int actions) {
     const int HID = (int)n.vfc1_w.size(1);
     return n.wino && (P == 3 || P == 17) && H >= 1 && W >= 1 && H <= 64 && W <= 64 && n.pc == 2 && n.vc == 1 &&
-           n.pfc_w.size(0) == (int64_t)2 * H * W && n.pfc_w.size(1) == actions && n.vfc1_w.size(0) == (int64_t)H * W && HID <= 256 &&
-           n.vfc2_w.numel() == HID && (size_t)(3 * 64 + 3 + (3 * H * W > 512 ? 8 : 16) * (3 * H * W + HID)) * 4 <= 64 * 1024 &&
+           n.pfc_w.size(0) == (int64_t)2 * H * W && n.pfc_w.size(1) == actions && n.vfc1_w.size(0) == (int64_t)H * W && HID <= 64 &&
+           n.vfc2_w.numel() == HID && (size_t)(3 * 64 + 3 + (3 * H * W > 512 ? 8 : 16) * (3 * H * W + 5 * 64)) * 4 <= 64 * 1024 &&
+           (size_t)((3 * H * W > 512 ? 8 : 16) * (2 * H * W + 128)) * 4 <= 64 * 1024 &&
            !getenv("SPRL_TORCH_NO_NCHW_NATIVE");
 }
 
@@ -346,6 +347,7 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
     if ((long long)cap * 64 * H * W * 4 >= 0x7fffff00LL || (long long)cap * H * W * P * 4 >= 0x40000000LL) return false;
     if (!mdl->nact[0].defined() || mdl->nact_boards < cap || mdl->nact_hw != (int64_t)H * W) {
         for (auto& t : mdl->nact) t = nchw_act(cap, H, W, opts);
+        mdl->npmaps = at::empty({ (int64_t)cap, (int64_t)2 * H * W }, opts);
         mdl->nact_boards = cap;
         mdl->nact_hw = (int64_t)H * W;
         (void)hipDeviceSynchronize();            // the buffers may be used on another stream than the one that allocated them
@@ -376,7 +378,7 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
     }
     return sprl_tail_nchw(x, n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(),
                           n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(), n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(),
-                          logits_out, value_out, cap, H, W, n.pc, n.vc, A, HID, batch_dev, stream) == 0;
+                          mdl->npmaps.data_ptr<float>(), logits_out, value_out, cap, H, W, n.pc, n.vc, A, HID, batch_dev, stream) == 0;
 }
 
 bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
