@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(256) tail_heads_value_kernel(const float* __re
                                                                const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
                                                                const float* __restrict__ vfc2_b, float* __restrict__ pmaps,
                                                                float* __restrict__ value, int batch, int HW, int PC, int HID,
-                                                               const unsigned* __restrict__ batch_dev) {
+                                                               const unsigned* __restrict__ batch_dev, int tile_m, int Wb) {
+    // tile_m = 0: x is NCHW; 3 / 4: x is layout T of the any-board trunk kernel (board width Wb)
     if (batch_dev) {
         const int real = (int)*batch_dev;
         batch = real < batch ? real : batch;
@@ -334,15 +335,30 @@ __global__ void __launch_bounds__(256) tail_heads_value_kernel(const float* __re
     // heads: thread = (board, cell); consecutive lanes read consecutive cells of one channel plane
     for (int e = tid; e < nb * HW; e += 256) {
         const int b = e / HW, cell = e - b * HW;
-        const float* xp = x + ((size_t)(n0 + b) * 64) * HW + cell;
         float acc[OC];
 #pragma unroll
         for (int o = 0; o < OC; ++o) acc[o] = 0.0f;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) {
-            const float v = xp[(size_t)c * HW];
+        if (tile_m) {
+            typedef float tf4 __attribute__((ext_vector_type(4)));
+            const int Hb = HW / Wb, row = cell / Wb, col = cell - row * Wb;
+            const int TXt = (Wb + tile_m - 1) / tile_m, TPB = TXt * ((Hb + tile_m - 1) / tile_m), MC = tile_m * tile_m;
+            const int cell_t = (row % tile_m) * tile_m + col % tile_m, tile_t = (row / tile_m) * TXt + col / tile_m;
+            const tf4* xp = (const tf4*)x + ((size_t)(n0 + b) * 16 * MC + cell_t) * TPB + tile_t;
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const tf4 v = xp[(size_t)q * MC * TPB];
 #pragma unroll
-            for (int o = 0; o < OC; ++o) acc[o] += s_hw[o * 64 + c] * v;
+                for (int o = 0; o < OC; ++o)
+                    acc[o] += s_hw[o * 64 + 4 * q] * v[0] + s_hw[o * 64 + 4 * q + 1] * v[1] + s_hw[o * 64 + 4 * q + 2] * v[2] + s_hw[o * 64 + 4 * q + 3] * v[3];
+            }
+        } else {
+            const float* xp = x + ((size_t)(n0 + b) * 64) * HW + cell;
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) {
+                const float v = xp[(size_t)c * HW];
+#pragma unroll
+                for (int o = 0; o < OC; ++o) acc[o] += s_hw[o * 64 + c] * v;
+            }
         }
 #pragma unroll
         for (int o = 0; o < OC; ++o) {
@@ -495,7 +511,8 @@ template <int P>
 __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __restrict__ planes, const float* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ y, long long cells, int H, int W,
-                                                             const unsigned* __restrict__ batch_dev) {
+                                                             const unsigned* __restrict__ batch_dev, int tile_m) {
+    // tile_m = 0: y is NCHW; 3 or 4: y is layout T of the any-board trunk kernel (cnn_wino.hip): [n][q][cell][tile][4 channels]
     constexpr int PG = (P + 3) / 4, KS = PG * 9;
     if (batch_dev) {                                   // the real board count is on the device; `cells` is the capacity
         const long long real = (long long)*batch_dev * H * W;
@@ -552,7 +569,22 @@ __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __r
             a = an;
         }
         // accumulator row r of block kb = channel 16 kb + 4 qs + r, column = this lane's cell
-        if (live) {
+        if (live && tile_m) {
+            // layout T: the four channels of a block (quad 4 kb + qs) of this cell are one 16-byte vector
+            const int TXt = (W + tile_m - 1) / tile_m, TPB = TXt * ((H + tile_m - 1) / tile_m), MC = tile_m * tile_m;
+            const int cell_t = (row % tile_m) * tile_m + col % tile_m, tile_t = (row / tile_m) * TXt + col / tile_m;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                stem_f4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * kb + 4 * qs + r;
+                    const float t = acc[kb][r] * scsh[0][k] + scsh[1][k];
+                    v[r] = t > 0.0f ? t : 0.0f;
+                }
+                *(stem_f4*)(y + ((((size_t)n * 16 + 4 * kb + qs) * MC + cell_t) * TPB + tile_t) * 4) = v;
+            }
+        } else if (live) {
             float* yo = y + ((size_t)n * 64) * HW + cell;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
@@ -566,18 +598,18 @@ __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __r
     }
 }
 
-extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, const float* scale, const float* shift, float* y,
-                                          long long batch, int P, int H, int W, const unsigned* batch_dev, void* stream) {
+static int stem_any_board(const float* planes, const float* w, const float* scale, const float* shift, float* y, long long batch, int P,
+                          int H, int W, const unsigned* batch_dev, int tile_m, void* stream) {
     if (batch <= 0) return 0;
     const long long cells = batch * H * W;
-    if (batch_dev && (cells * P * 4 >= 0x40000000LL || (P != 3 && P != 17))) return -1;      // only the MFMA form reads the count
-    if (cells * P * 4 < 0x40000000LL && (batch_dev || !getenv("SPRL_STEM_VALU"))) {
+    if ((batch_dev || tile_m) && (cells * P * 4 >= 0x40000000LL || (P != 3 && P != 17))) return -1;   // only the MFMA form does these
+    if (cells * P * 4 < 0x40000000LL && (batch_dev || tile_m || !getenv("SPRL_STEM_VALU"))) {
         long long blocks = (cells / 16 + 3) / 4;
         if (blocks > 256 * 6) blocks = 256 * 6;        // grid-stride over 16-cell tiles: the weight fragments are staged once per workgroup
         if (blocks < 1) blocks = 1;
         const dim3 g((unsigned)blocks), bl(256);
-        if (P == 3) hipLaunchKernelGGL(stem_mfma_nchw_kernel<3>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W, batch_dev);
-        else if (P == 17) hipLaunchKernelGGL(stem_mfma_nchw_kernel<17>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W, batch_dev);
+        if (P == 3) hipLaunchKernelGGL(stem_mfma_nchw_kernel<3>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W, batch_dev, tile_m);
+        else if (P == 17) hipLaunchKernelGGL(stem_mfma_nchw_kernel<17>, g, bl, 0, (hipStream_t)stream, planes, w, scale, shift, y, cells, H, W, batch_dev, tile_m);
         else return -1;
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
@@ -587,9 +619,19 @@ extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, c
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                          long long batch, int P, int H, int W, const unsigned* batch_dev, void* stream) {
+    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, batch_dev, 0, stream);
+}
 extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                       long long batch, int P, int H, int W, void* stream) {
-    return sprl_stem_conv3x3_nchw_dev(planes, w, scale, shift, y, batch, P, H, W, nullptr, stream);
+    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, nullptr, 0, stream);
+}
+// the same stem writing layout T (tile = 3 or 4) for the any-board trunk kernel
+extern "C" int sprl_stem_conv3x3_t(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                   long long batch, int P, int H, int W, int tile, const unsigned* batch_dev, void* stream) {
+    if (tile != 3 && tile != 4) return -1;
+    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, batch_dev, tile, stream);
 }
 
 extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
@@ -701,10 +743,9 @@ extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* h
 // (transposed Linear weight), vfc1_w: [VC*H*W][HID], vfc2_w: [HID]; pmaps: scratch [batch][PC*H*W]; logits: [batch][A], value:
 // [batch]; batch_dev: optional device pointer to the real board count (<= batch).  -1: shape not covered (the caller falls back
 // to the library GEMMs).
-extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
-                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* pmaps,
-                              float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
-                              const unsigned* batch_dev, void* stream) {
+static int tail_any_board(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b, const float* vfc1_w,
+                          const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* pmaps, float* logits, float* value,
+                          int batch, int H, int W, int PC, int VC, int A, int HID, const unsigned* batch_dev, int tile_m, void* stream) {
     if (batch <= 0) return 0;
     const int OC = PC + VC, HW = H * W, PIN = PC * HW;
     if (OC != 3 || PC != 2 || HID > 64) return -1;
@@ -717,12 +758,29 @@ extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, 
     hipStream_t st = (hipStream_t)stream;
     if (big) {
         hipLaunchKernelGGL((tail_heads_value_kernel<3, 8>), grid_a, block, lds_a, st, x, hw, hb, vfc1_w, vfc1_b, vfc2_w, vfc2_b, pmaps, value,
-                           batch, HW, PC, HID, batch_dev);
+                           batch, HW, PC, HID, batch_dev, tile_m, W);
         hipLaunchKernelGGL((policy_fc_kernel<8>), grid_b, block, lds_b, st, pmaps, pfc_w, pfc_b, logits, batch, PIN, A, batch_dev);
     } else {
         hipLaunchKernelGGL((tail_heads_value_kernel<3, 16>), grid_a, block, lds_a, st, x, hw, hb, vfc1_w, vfc1_b, vfc2_w, vfc2_b, pmaps, value,
-                           batch, HW, PC, HID, batch_dev);
+                           batch, HW, PC, HID, batch_dev, tile_m, W);
         hipLaunchKernelGGL((policy_fc_kernel<16>), grid_b, block, lds_b, st, pmaps, pfc_w, pfc_b, logits, batch, PIN, A, batch_dev);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
+                              const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* pmaps,
+                              float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
+                              const unsigned* batch_dev, void* stream) {
+    return tail_any_board(x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, pmaps, logits, value, batch, H, W, PC, VC, A, HID,
+                          batch_dev, 0, stream);
+}
+// the same tail on a trunk output in layout T (tile = 3 or 4)
+extern "C" int sprl_tail_t(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
+                           const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* pmaps,
+                           float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID, int tile,
+                           const unsigned* batch_dev, void* stream) {
+    if (tile != 3 && tile != 4) return -1;
+    return tail_any_board(x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, pmaps, logits, value, batch, H, W, PC, VC, A, HID,
+                          batch_dev, tile, stream);
 }

@@ -390,7 +390,60 @@ __device__ __forceinline__ void inverse_transform3(const float (&m)[5][5], float
     }
 }
 
-template <int M, int OCC, int RES>
+// Rows [I0, I0 + NR) of Y = A^T m A (the output stage of layout T works on row bands so that a band's four channels can be
+// stored as 16-byte vectors without holding the whole tile of all four channels in registers)
+template <int M, int I0, int NR>
+__device__ __forceinline__ void inverse_rows(const float (&m)[M + 2][M + 2], float (&o)[NR][M]) {
+    constexpr int PT = M + 2;
+    float tm[NR][PT];
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+        const float s12 = m[1][b] + m[2][b], d12 = m[1][b] - m[2][b];
+        if constexpr (M == 4) {
+            const float s34 = m[3][b] + m[4][b], d34 = m[3][b] - m[4][b];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int row = I0 + i;
+                tm[i][b] = row == 0 ? m[0][b] + s12 + s34 : row == 1 ? __builtin_fmaf(2.0f, d34, d12)
+                         : row == 2 ? __builtin_fmaf(4.0f, s34, s12) : __builtin_fmaf(8.0f, d34, d12) + m[5][b];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int row = I0 + i;
+                tm[i][b] = row == 0 ? m[0][b] + s12 + m[3][b] : row == 1 ? __builtin_fmaf(2.0f, m[3][b], d12)
+                                                                          : __builtin_fmaf(4.0f, m[3][b], s12) + m[4][b];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const float s12 = tm[i][1] + tm[i][2], d12 = tm[i][1] - tm[i][2];
+        if constexpr (M == 4) {
+            const float s34 = tm[i][3] + tm[i][4], d34 = tm[i][3] - tm[i][4];
+            o[i][0] = tm[i][0] + s12 + s34;
+            o[i][1] = __builtin_fmaf(2.0f, d34, d12);
+            o[i][2] = __builtin_fmaf(4.0f, s34, s12);
+            o[i][3] = __builtin_fmaf(8.0f, d34, d12) + tm[i][5];
+        } else {
+            o[i][0] = tm[i][0] + s12 + tm[i][3];
+            o[i][1] = __builtin_fmaf(2.0f, tm[i][3], d12);
+            o[i][2] = __builtin_fmaf(4.0f, tm[i][3], s12) + tm[i][4];
+        }
+    }
+}
+
+// LAY = 0: NCHW activations (the round-2 form: patch rows gathered 16 + 8 bytes at a time at 4-byte alignment, outputs stored one
+//          float at a time).  tools/nchw_lab.py (profiles/r03h_nchw_lab_*.log) showed that form bound by its memory INSTRUCTIONS,
+//          not by bandwidth or MFMA: at 8192 9x9 boards 361 us, of which the output stores 96 us, the activation loads 89 us, the
+//          residual loads 49 us - while the MFMA loop + transforms alone run in 185 us.
+// LAY = 1: layout T, made for this kernel:  x[n][q][cell][tile][e]  with channel 4 q + e, cell = i * M + j inside the M x M tile,
+//          tile = ty * TX + tx; 64 * M^2 * tiles floats per board (9x9 with M = 3: exactly 64 * 81, no padding; 19x19 with M = 4:
+//          64 * 400).  Every global access is then an aligned 16-byte vector of four channels, and lanes that hold neighbouring
+//          tiles touch neighbouring vectors: a patch is (M+2)^2 vector loads shared over 8 loader threads per (tile, channel quad),
+//          an output tile M^2 vector stores, the residual M^2 vector loads.  Cells of a tile that lie off the board are never read
+//          (the loader answers them with zero through the range check) and may hold anything.
+template <int M, int OCC, int RES, int LAY>
 __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     const float* __restrict__ res, float* __restrict__ y, int batch,
@@ -425,7 +478,9 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
 
     // chunk = groups 2c, 2c+1: 8 channel slots x 16 tiles x NP patch values.  Loader thread = (tile, slot, half): the patch
     // rows 3 half .. 3 half + 2 of one (channel slot, tile) (M = 3, half 1: rows 3 and 4)
+    constexpr int MC = M * M, NPC = (NP + 7) / 8;     // layout T: cells per tile, patch cells per loader thread
     const int ld_tile = tl, ld_slot = (tid >> 4) & 7, ld_half = tid >> 7;
+    const int ld_quad = (tid >> 4) & 1, ld_part = tid >> 5;      // layout T: loader thread = (tile, channel quad of the chunk, part)
     const int ld_n = t_n;
     const int ld_row = t_row0 - 1 + 3 * ld_half, ld_col = t_col0 - 1;
     const int ld_lds = ld_slot * SS + ld_tile * PS + 3 * PT * ld_half;
@@ -434,15 +489,16 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     // past the batch) gets bit 31 set in its offset, which the hardware range check answers with 0 for loads and drops for
     // stores (the host keeps the tensors below 2 GiB) - no predicated loads, no branches, no 64-bit address arithmetic.
     constexpr int OOB = (int)0x80000000;
-    const unsigned act_bytes = (unsigned)batch * 64u * (unsigned)HW * 4u;
+    const unsigned act_bytes = LAY ? (unsigned)batch * (unsigned)(64 * MC * TPB * 4) : (unsigned)batch * 64u * (unsigned)HW * 4u;
     // the input descriptor starts 16 bytes before x: a patch's first column is col0 - 1, so with the bias no offset is ever
     // negative (a negative per-lane offset plus a positive instruction offset must not depend on how the range check wraps)
     // A patch row (6 or 5 floats) is one 16-byte + one 8- or 4-byte load and a residual row one 16-byte load, at 4-byte alignment;
     // at a board's edge they run into the next row / plane (those values are replaced by zeros below / never stored) and at the
     // very end of the tensor up to 20 bytes past it, at its very start 4 bytes before it (the left neighbour of column 0): x must
     // be readable from 16 bytes before its start, x and res for 32 bytes beyond their end (SLACK_G).
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x - 16), 0, act_bytes + 16u + SLACK_G, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes + SLACK_G : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = LAY ? __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, act_bytes, 0x00020000)
+                                          : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x - 16), 0, act_bytes + 16u + SLACK_G, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes + (LAY ? 0u : SLACK_G) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, act_bytes, 0x00020000);
     int ld_rowoff[3];
     bool ld_colok[PT];
@@ -454,12 +510,30 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         // (board, channel slot 0 of the chunk, row, first patch column) in bytes; the chunk's channel is added per load
         ld_rowoff[i] = (ld_n >= 0 && row >= 0 && row < H && i < ld_rows) ? ((ld_n * 64) * HW + row * W + ld_col) * 4 + 16 : OOB;
     }
-    float pre[NLD];
+    // layout T: byte offset of (board, quad ld_quad, patch cell) for this thread's patch cells pc = ld_part, ld_part + 8, ...;
+    // the chunk's first quad (2 * chunk) is added as the instructions' scalar offset
+    int ld_toff[NPC];
+#pragma unroll
+    for (int e = 0; e < NPC; ++e) {
+        const int pc = ld_part + 8 * e;
+        const int R = t_row0 + pc / PT - 1, Cc = t_col0 + pc % PT - 1;
+        const bool ok = LAY && pc < NP && t_n >= 0 && R >= 0 && R < H && Cc >= 0 && Cc < W;
+        ld_toff[e] = ok ? (((t_n * 16 + ld_quad) * MC + (R % M) * M + Cc % M) * TPB + (R / M) * TX + Cc / M) * 16 : OOB;
+    }
+    float pre[LAY ? 4 * NPC : NLD];
     auto gload = [&](int chunk) {
+        if (LAB_OFF(0)) return;                        // lab: no activation loads
+        if constexpr (LAY == 1) {
+#pragma unroll
+            for (int e = 0; e < NPC; ++e) {
+                const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_toff[e], chunk * (2 * MC * 16) * TPB, 0));
+                pre[4 * e] = v[0]; pre[4 * e + 1] = v[1]; pre[4 * e + 2] = v[2]; pre[4 * e + 3] = v[3];
+            }
+            return;
+        }
         const int g = 2 * chunk + (ld_slot >> 2);
         const int k = 16 * (g >> 2) + 4 * (ld_slot & 3) + (g & 3);
         const int koff = k * HW * 4;
-        if (LAB_OFF(0)) return;                        // lab: no activation loads
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const f4 a4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_rowoff[i] + koff, 0, 0));
@@ -474,6 +548,17 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     };
     auto lstore = [&](float* buf) {
         if (LAB_OFF(1)) return;                        // lab: no patch stores to LDS
+        if constexpr (LAY == 1) {
+#pragma unroll
+            for (int e = 0; e < NPC; ++e) {
+                const int pc = ld_part + 8 * e;
+                if (pc < NP) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) buf[(ld_quad * 4 + ch) * SS + ld_tile * PS + pc] = pre[4 * e + ch];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
             if (M == 4 || q < 2 * PT || ld_half == 0) buf[ld_lds + q] = ld_colok[q % PT] ? pre[q] : 0.0f;      // columns off the board
@@ -602,6 +687,49 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     kstep(v_buf, 0, std::true_type{});
     for (int c = 0; c < 8; ++c) phase(c);
 
+    if constexpr (LAY == 1) {
+        // ---- layout T: inverse transform per row band, the four channels of a cell leave as one 16-byte vector ----
+        constexpr int NR = M == 4 ? 2 : M;             // rows per band: M = 3 one band of the whole tile, M = 4 two bands of two rows
+        const int q_out = 4 * kb + c_sub;              // this lane's output channels: 4 q_out .. 4 q_out + 3  (component r)
+        const int obase = t_n >= 0 ? ((t_n * 16 + q_out) * MC * TPB + t_tt) * 16 : OOB;
+        const f4 sc4 = *(const f4*)(scale + 4 * q_out), sh4 = *(const f4*)(shift + 4 * q_out);
+        const float relu_floor = relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+        for (int band = 0; band < M / NR; ++band) {
+            f4 outv[NR * M], rv[NR * M];
+            if (RES) {
+#pragma unroll
+                for (int c = 0; c < NR * M; ++c)
+                    rv[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + (band * NR * M + c) * TPB * 16, 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m[PT][PT];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) m[p / PT][p % PT] = acc[p][r];
+                float o[NR][M];
+                if (band == 0) inverse_rows<M, 0, NR>(m, o);
+                else inverse_rows<M, (M == 4 ? 2 : 0), NR>(m, o);
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+#pragma unroll
+                    for (int j = 0; j < M; ++j) outv[i * M + j][r] = __builtin_fmaf(o[i][j], sc4[r], sh4[r]);
+            }
+#pragma unroll
+            for (int c = 0; c < NR * M; ++c) {
+                f4 v = outv[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (RES) v[r] += rv[c][r];
+                    v[r] = __builtin_fmaxf(v[r], relu_floor);
+                }
+                if (LAB_OFF(4) && v[0] != 12345.0f) continue;      // lab: no output stores
+                // (per-lane offset + nothing else: no scalar-register offset on a 16-byte store - the gfx950 store hazard)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, obase + (band * NR * M + c) * TPB * 16, 0, 0);
+            }
+        }
+        return;
+    }
     // ---- inverse transform in registers + epilogue, NCHW ----
     // byte offset of (board, channel 0, row0 + i, col0) per output row, bit 31 set when the row is off the board / past the batch
     int o_rowoff[M], o_colsel[M];
@@ -714,30 +842,48 @@ extern "C" int sprl_wino_nchw_tile(int H, int W) {
     const long long w4 = (long long)((H + 3) / 4) * ((W + 3) / 4) * 36, w3 = (long long)((H + 2) / 3) * ((W + 2) / 3) * 25;
     return w3 < w4 ? 3 : 4;
 }
-extern "C" int sprl_wino_conv64_nchw_tiled(const float* x, const float* u, const float* scale, const float* shift, const float* res,
-                                           float* y, int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream) {
+static int launch_any_board(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y, int batch,
+                            int H, int W, int relu, int tile, int layout_t, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     if (H < 1 || W < 1 || H > 64 || W > 64 || (tile != 3 && tile != 4)) return -1;
     const long long tiles = (long long)batch * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
     if (tiles > 0x7fffffffLL - 16) return -1;
-    if ((long long)batch * 64 * H * W * 4 >= 0x7fffff00LL) return -1;   // per-lane byte offsets: bit 31 marks "off the board"
+    const long long board_floats = layout_t ? 64LL * tile * tile * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) : 64LL * H * W;
+    if ((long long)batch * board_floats * 4 >= 0x7fffff00LL) return -1;   // per-lane byte offsets: bit 31 marks "off the board"
     const dim3 grid((unsigned)((tiles + 15) / 16)), block(NTHR2);
     // F(3x3): 50 KB of LDS per workgroup, so three fit a CU if the kernel is held to 168 registers (11 of them then spill);
     // SPRL_WINO_F3_OCC=2 selects the two-per-CU build without spills (measured: DESIGN.md section 5)
     static const int f3_occ = getenv("SPRL_WINO_F3_OCC") ? atoi(getenv("SPRL_WINO_F3_OCC")) : 3;
     // RES = 0: the first convolution of a residual block has no residual input - no loads, no adds for it
-#define SPRL_LAUNCH_NCHW(MM, OO)                                                                                                          \
+#define SPRL_LAUNCH_NCHW(MM, OO, LL)                                                                                                      \
     do {                                                                                                                                  \
         if (res)                                                                                                                          \
-            hipLaunchKernelGGL((wino_conv64_nchw_kernel<MM, OO, 1>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev); \
+            hipLaunchKernelGGL((wino_conv64_nchw_kernel<MM, OO, 1, LL>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev); \
         else                                                                                                                              \
-            hipLaunchKernelGGL((wino_conv64_nchw_kernel<MM, OO, 0>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev); \
+            hipLaunchKernelGGL((wino_conv64_nchw_kernel<MM, OO, 0, LL>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev); \
     } while (0)
-    if (tile == 4) SPRL_LAUNCH_NCHW(4, 2);
-    else if (f3_occ == 2) SPRL_LAUNCH_NCHW(3, 2);
-    else SPRL_LAUNCH_NCHW(3, 3);
+    if (layout_t) {
+        if (tile == 4) SPRL_LAUNCH_NCHW(4, 2, 1);
+        else if (f3_occ == 2) SPRL_LAUNCH_NCHW(3, 2, 1);
+        else SPRL_LAUNCH_NCHW(3, 3, 1);
+    } else {
+        if (tile == 4) SPRL_LAUNCH_NCHW(4, 2, 0);
+        else if (f3_occ == 2) SPRL_LAUNCH_NCHW(3, 2, 0);
+        else SPRL_LAUNCH_NCHW(3, 3, 0);
+    }
 #undef SPRL_LAUNCH_NCHW
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int sprl_wino_conv64_nchw_tiled(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                           float* y, int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream) {
+    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 0, batch_dev, stream);
+}
+// Activations in layout T (see the kernel): x, res, y hold sprl_wino_t_board_floats(H, W, tile) floats per board; `u` from
+// sprl_wino_transform_weights_t (input channels of K step s are 4 s .. 4 s + 3).
+extern "C" int sprl_wino_t_board_floats(int H, int W, int tile) { return 64 * tile * tile * ((H + tile - 1) / tile) * ((W + tile - 1) / tile); }
+extern "C" int sprl_wino_conv64_t(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y,
+                                  int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream) {
+    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 1, batch_dev, stream);
 }
 // F(4x4,3x3) tiling, as before
 extern "C" int sprl_wino_conv64_nchw_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,

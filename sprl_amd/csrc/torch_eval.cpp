@@ -33,6 +33,15 @@ extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float
 extern "C" int sprl_wino_conv64_nchw_tiled(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                            float* y, int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_wino_nchw_tile(int H, int W);
+extern "C" int sprl_wino_t_board_floats(int H, int W, int tile);
+extern "C" int sprl_wino_conv64_t(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y,
+                                  int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_stem_conv3x3_t(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                   long long batch, int P, int H, int W, int tile, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_tail_t(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
+                           const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b, float* pmaps,
+                           float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID, int tile,
+                           const unsigned* batch_dev, void* stream);
 extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                           long long batch, int P, int H, int W, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_tail_nchw(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
@@ -63,8 +72,10 @@ namespace {
 struct NativeNet {
     bool ok = false;
     at::Tensor stem_w, stem_scale, stem_shift;
-    struct Block { at::Tensor w1, s1, t1, w2, s2, t2, u1, u2, u1t3, u2t3; };   // u*: Winograd-domain weights (cnn_wino.hip);
-                                                                               // u*t3: for the F(3x3,3x3) tiling, built on first use
+    struct Block { at::Tensor w1, s1, t1, w2, s2, t2, u1, u2, u1t, u2t; };     // u*: Winograd-domain weights (cnn_wino.hip);
+                                                                               // u*t: for the any-board kernel on layout T in the
+                                                                               // tiling `ut_tile`, built on first use
+    int ut_tile = 0;
     bool wino = false;              // every trunk convolution is 64 -> 64: the hand-written Winograd/MFMA kernel applies
     std::vector<Block> blocks;
     at::Tensor pconv_w, pconv_b, pfc_w, pfc_b, vconv_w, vconv_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b;
@@ -127,7 +138,7 @@ bool fold_bn(const std::map<std::string, at::Tensor>& t, const std::string& conv
 // U2[p = xi * 6 + nu][s][kb][lane] with output channel k = 16 kb + lane % 16, input channel = slot lane / 16 of group s.
 // F(3x3, 3x3) (interpolation points 0, 1, -1, 2, inf; the kernel's B^T and A^T are in cnn_wino.hip): U = G g G^T is 5x5, stored
 // as U4[p / 4][s][kb][lane][p % 4] with 7 quads (positions 25..27 are zero and never multiplied).
-void wino_transform_f3(const float* g, float* up) {
+void wino_transform_f3(const float* g, float* up, bool quad_order = false) {
     static const double G[5][3] = { { 1.0 / 2, 0, 0 }, { 1.0 / 2, 1.0 / 2, 1.0 / 2 }, { 1.0 / 6, -1.0 / 6, 1.0 / 6 }, { 1.0 / 6, 1.0 / 3, 2.0 / 3 }, { 0, 0, 1 } };
     for (size_t i = 0; i < (size_t)7 * 16 * 4 * 64 * 4; ++i) up[i] = 0.0f;
     for (int k = 0; k < 64; ++k)
@@ -139,13 +150,16 @@ void wino_transform_f3(const float* g, float* up) {
             for (int a = 0; a < 5; ++a)
                 for (int b = 0; b < 5; ++b) {
                     const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
-                    const int p = a * 5 + b, s = 4 * (c >> 4) + (c & 3), kb = k >> 4, lane = ((c >> 2) & 3) * 16 + (k & 15);
+                    // K step s reads input channels 16 (s >> 2) + 4 slot + (s & 3) (layout W / NCHW kernels) or, with quad_order,
+                    // 4 s + slot (layout T: a K step is one channel quad)
+                    const int s = quad_order ? c >> 2 : 4 * (c >> 4) + (c & 3), slot = quad_order ? c & 3 : (c >> 2) & 3;
+                    const int p = a * 5 + b, kb = k >> 4, lane = slot * 16 + (k & 15);
                     up[((((size_t)(p >> 2) * 16 + s) * 4 + kb) * 64 + lane) * 4 + (p & 3)] = (float)v;
                 }
         }
 }
 
-void wino_transform(const float* g, float* up) {
+void wino_transform(const float* g, float* up, bool quad_order = false) {
     const bool packed4 = sprl_wino_weight_layout() == 2;       // U4[p / 4][s][kb][lane][p % 4] instead of U2[p][s][kb][lane]
     static const double G[6][3] = { { 1.0 / 4, 0, 0 },         { -1.0 / 6, -1.0 / 6, -1.0 / 6 }, { -1.0 / 6, 1.0 / 6, -1.0 / 6 },
                                     { 1.0 / 24, 1.0 / 12, 1.0 / 6 }, { 1.0 / 24, -1.0 / 12, 1.0 / 6 }, { 0, 0, 1 } };
@@ -159,18 +173,19 @@ void wino_transform(const float* g, float* up) {
                 for (int b = 0; b < 6; ++b) {
                     const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
                     // K-loop step s reads group s of layout W: input channel c = 16 (s >> 2) + 4 slot + (s & 3)
-                    const int p = a * 6 + b, s = 4 * (c >> 4) + (c & 3), kb = k >> 4, lane = ((c >> 2) & 3) * 16 + (k & 15);
+                    const int s = quad_order ? c >> 2 : 4 * (c >> 4) + (c & 3), slot = quad_order ? c & 3 : (c >> 2) & 3;
+                    const int p = a * 6 + b, kb = k >> 4, lane = slot * 16 + (k & 15);
                     if (packed4) up[((((size_t)(p >> 2) * 16 + s) * 4 + kb) * 64 + lane) * 4 + (p & 3)] = (float)v;
                     else up[(((size_t)p * 16 + s) * 4 + kb) * 64 + lane] = (float)v;
                 }
         }
 }
 
-at::Tensor wino_weights(const at::Tensor& w_dev, int tile = 4) {
+at::Tensor wino_weights(const at::Tensor& w_dev, int tile = 4, bool quad_order = false) {
     at::Tensor w = w_dev.to(at::kCPU, at::kFloat).contiguous();
     at::Tensor u = at::empty({ (tile == 3 ? 28 : 36) * 64 * 64 }, at::TensorOptions().dtype(at::kFloat));
-    if (tile == 3) wino_transform_f3(w.data_ptr<float>(), u.data_ptr<float>());
-    else wino_transform(w.data_ptr<float>(), u.data_ptr<float>());
+    if (tile == 3) wino_transform_f3(w.data_ptr<float>(), u.data_ptr<float>(), quad_order);
+    else wino_transform(w.data_ptr<float>(), u.data_ptr<float>(), quad_order);
     return u.to(w_dev.device());
 }
 
@@ -335,33 +350,35 @@ bool nchw_covered(const NativeNet& n, int P, int H, int W, int actions) {
 bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W, ConvProfile* prof, float* logits_out,
                   float* value_out, const unsigned* batch_dev, void* stream, const at::TensorOptions& opts) {
     const int tile = sprl_wino_nchw_tile(H, W);
-    if (tile == 3 && !mdl->native.blocks.empty() && !mdl->native.blocks[0].u1t3.defined()) {     // first 9x9-class board on this model
+    if (mdl->native.ut_tile != tile) {               // first board of this tiling on this model: filters for the layout-T kernel
         for (auto& b : mdl->native.blocks) {
-            b.u1t3 = wino_weights(b.w1, 3);
-            b.u2t3 = wino_weights(b.w2, 3);
+            b.u1t = wino_weights(b.w1, tile, true);
+            b.u2t = wino_weights(b.w2, tile, true);
         }
+        mdl->native.ut_tile = tile;
         (void)hipDeviceSynchronize();
     }
     const NativeNet& n = mdl->native;
+    const int64_t board_floats = sprl_wino_t_board_floats(H, W, tile);
     const int A = (int)n.pfc_w.size(1), HID = (int)n.vfc1_w.size(1);
-    if ((long long)cap * 64 * H * W * 4 >= 0x7fffff00LL || (long long)cap * H * W * P * 4 >= 0x40000000LL) return false;
+    if ((long long)cap * board_floats * 4 >= 0x7fffff00LL || (long long)cap * H * W * P * 4 >= 0x40000000LL) return false;
     if (!mdl->nact[0].defined() || mdl->nact_boards < cap || mdl->nact_hw != (int64_t)H * W) {
-        for (auto& t : mdl->nact) t = nchw_act(cap, H, W, opts);
+        for (auto& t : mdl->nact) t = at::empty({ (int64_t)cap * board_floats }, opts);      // layout T (cnn_wino.hip)
         mdl->npmaps = at::empty({ (int64_t)cap, (int64_t)2 * H * W }, opts);
         mdl->nact_boards = cap;
         mdl->nact_hw = (int64_t)H * W;
         (void)hipDeviceSynchronize();            // the buffers may be used on another stream than the one that allocated them
     }
     float *x = mdl->nact[0].data_ptr<float>(), *ya = mdl->nact[1].data_ptr<float>(), *za = mdl->nact[2].data_ptr<float>();
-    if (sprl_stem_conv3x3_nchw_dev(planes, n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(), n.stem_shift.data_ptr<float>(), x,
-                                   cap, P, H, W, batch_dev, stream) != 0)
+    if (sprl_stem_conv3x3_t(planes, n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(), n.stem_shift.data_ptr<float>(), x, cap, P, H, W,
+                            tile, batch_dev, stream) != 0)
         return false;
     auto conv = [&](const float* src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res, float* dst) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
         if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
-        const int rc = sprl_wino_conv64_nchw_tiled(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1,
-                                                   tile, batch_dev, stream);
+        const int rc = sprl_wino_conv64_t(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1, tile,
+                                          batch_dev, stream);
         if (timed) {
             (void)hipEventRecord(e1, (hipStream_t)stream);
             prof->ev.push_back(e0);
@@ -373,12 +390,12 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
         return rc == 0;
     };
     for (const auto& b : n.blocks) {
-        if (!conv(x, tile == 3 ? b.u1t3 : b.u1, b.s1, b.t1, nullptr, ya) || !conv(ya, tile == 3 ? b.u2t3 : b.u2, b.s2, b.t2, x, za)) return false;
+        if (!conv(x, b.u1t, b.s1, b.t1, nullptr, ya) || !conv(ya, b.u2t, b.s2, b.t2, x, za)) return false;
         std::swap(x, za);
     }
-    return sprl_tail_nchw(x, n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(),
-                          n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(), n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(),
-                          mdl->npmaps.data_ptr<float>(), logits_out, value_out, cap, H, W, n.pc, n.vc, A, HID, batch_dev, stream) == 0;
+    return sprl_tail_t(x, n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(),
+                       n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(), n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(),
+                       mdl->npmaps.data_ptr<float>(), logits_out, value_out, cap, H, W, n.pc, n.vc, A, HID, tile, batch_dev, stream) == 0;
 }
 
 bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Tensor& value, ConvProfile* prof,
@@ -610,6 +627,11 @@ static int forward_common(void* handle, const float* planes, int batch, int npla
 void sprl_wino_transform_weights(const float* w, float* u) { wino_transform(w, u); }
 // the same for the F(3x3,3x3) tiling of the any-board kernel (28*64*64 floats)
 void sprl_wino_transform_weights_f3(const float* w, float* u) { wino_transform_f3(w, u); }
+// for the any-board kernel on layout T (a K step = one channel quad): tile 4 -> 36*64*64 floats, tile 3 -> 28*64*64
+void sprl_wino_transform_weights_t(const float* w, float* u, int tile) {
+    if (tile == 3) wino_transform_f3(w, u, true);
+    else wino_transform(w, u, true);
+}
 
 // profile mode: time every trunk-convolution launch with HIP events; totals since load (ms, launches, boards)
 void sprl_torch_profile_enable(void* handle, int on) { static_cast<Model*>(handle)->prof.on = on != 0; }

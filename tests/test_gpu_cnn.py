@@ -22,6 +22,9 @@ def plug():
     p.sprl_wino_conv64_nchw.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
     p.sprl_wino_conv64_nchw_tiled.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
     p.sprl_wino_transform_weights_f3.argtypes = [C.c_void_p, C.c_void_p]
+    p.sprl_wino_conv64_t.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
+    p.sprl_wino_transform_weights_t.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    p.sprl_stem_conv3x3_t.argtypes = [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return p
 
 
@@ -145,6 +148,89 @@ def test_wino_conv_general_boards_nchw(plug, H, W, B, tile):
         assert rc == 0
         torch.cuda.synchronize()
         assert torch.equal(y2[:live], y[:live]) and torch.isnan(y2[live:]).all()
+
+
+def to_layout_t(x, M):
+    """[B][64][H][W] -> layout T of the any-board trunk kernel: [B][q = 16][cell = M*M][tile][4 channels] (cnn_wino.hip)."""
+    import torch
+    B, _, H, W = x.shape
+    TY, TX = (H + M - 1) // M, (W + M - 1) // M
+    xp = torch.zeros(B, 64, TY * M, TX * M, device=x.device, dtype=x.dtype)
+    xp[:, :, :H, :W] = x
+    return xp.view(B, 16, 4, TY, M, TX, M).permute(0, 1, 4, 6, 3, 5, 2).reshape(B, 16, M * M, TY * TX, 4).contiguous()
+
+
+def from_layout_t(t, M, H, W):
+    B = t.shape[0]
+    TY, TX = (H + M - 1) // M, (W + M - 1) // M
+    return t.view(B, 16, M, M, TY, TX, 4).permute(0, 1, 6, 4, 2, 5, 3).reshape(B, 64, TY * M, TX * M)[:, :, :H, :W]
+
+
+@pytest.mark.parametrize("tile", [4, 3])
+@pytest.mark.parametrize("H,W,B", [(9, 9, 7), (19, 19, 3), (8, 8, 5), (5, 7, 9), (9, 9, 300), (19, 19, 40), (13, 6, 11)])
+def test_wino_conv_general_boards_layout_t(plug, H, W, B, tile):
+    """The any-board kernel on layout T (aligned 16-byte vectors of four channels, the product path for Go 9x9 / 19x19): both
+    tilings on every board against conv2d in float64; cells of the tiles that lie off the board hold NaN in the inputs (they must
+    never be read); board count from the host and from device memory."""
+    import torch
+    torch.manual_seed(H * 1000 + W * 10 + B + tile)
+
+    def act():
+        x = torch.randn(B, 64, H, W, device="cuda")
+        t = to_layout_t(x, tile)
+        mask = to_layout_t(torch.ones_like(x), tile)
+        return x, torch.where(mask > 0, t, torch.full_like(t, float("nan")))
+
+    x, xt = act()
+    res, rest = act()
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.06
+    scale = torch.rand(64, device="cuda") + 0.5
+    shift = torch.randn(64, device="cuda") * 0.3
+    u = np.zeros((36 if tile == 4 else 28) * 64 * 64, np.float32)
+    wc = np.ascontiguousarray(w.cpu().numpy())
+    plug.sprl_wino_transform_weights_t(wc.ctypes.data, u.ctypes.data, tile)
+    ud = torch.from_numpy(u).cuda()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    for use_res, relu in ((True, True), (False, False)):
+        want = ref + res.double() if use_res else ref
+        if relu:
+            want = torch.relu(want)
+        yt = torch.full_like(xt, float("nan"))
+        rc = plug.sprl_wino_conv64_t(xt.data_ptr(), ud.data_ptr(), scale.data_ptr(), shift.data_ptr(), rest.data_ptr() if use_res else None,
+                                     yt.data_ptr(), B, H, W, int(relu), tile, None, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        y = from_layout_t(yt, tile, H, W)
+        err = (y.double() - want).abs().max().item()
+        assert err < 8e-5, (H, W, B, tile, use_res, relu, err)
+        live = max(1, B // 2)
+        cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+        y2t = torch.full_like(xt, float("nan"))
+        rc = plug.sprl_wino_conv64_t(xt.data_ptr(), ud.data_ptr(), scale.data_ptr(), shift.data_ptr(), rest.data_ptr() if use_res else None,
+                                     y2t.data_ptr(), B, H, W, int(relu), tile, cnt.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(from_layout_t(y2t[:live], tile, H, W), y[:live]) and torch.isnan(y2t[live:]).all()
+
+
+@pytest.mark.parametrize("P,H,W,B,tile", [(17, 9, 9, 7, 3), (17, 19, 19, 3, 4), (3, 13, 6, 11, 4), (17, 9, 9, 513, 3), (3, 9, 9, 1, 4)])
+def test_stem_any_board_layout_t(plug, P, H, W, B, tile):
+    """The MFMA stem writing layout T: same values as conv2d in float64 once the layout is undone."""
+    import torch
+    torch.manual_seed(P * 100 + H + B)
+    x = (torch.rand(B, P, H, W, device="cuda") < 0.4).float() + 0.25 * torch.randn(B, P, H, W, device="cuda")
+    w = torch.randn(64, P, 3, 3, device="cuda") * 0.2
+    scale = torch.rand(64, device="cuda") + 0.5
+    shift = torch.randn(64, device="cuda") * 0.3
+    want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1)
+                      + shift.double().view(1, -1, 1, 1))
+    TY, TX = (H + tile - 1) // tile, (W + tile - 1) // tile
+    yt = torch.full((B, 16, tile * tile, TY * TX, 4), float("nan"), device="cuda")
+    rc = plug.sprl_stem_conv3x3_t(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(), yt.data_ptr(), B, P, H, W, tile, None, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (from_layout_t(yt, tile, H, W).double() - want).abs().max().item()
+    assert err < 1e-5, (P, H, W, B, tile, err)
 
 
 @pytest.mark.parametrize("P,H,W,B", [(17, 9, 9, 7), (17, 19, 19, 3), (3, 13, 6, 11), (17, 9, 9, 513), (3, 9, 9, 1)])

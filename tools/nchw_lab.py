@@ -22,7 +22,7 @@ def build():
                                "-DSPRL_WINO_LAB", "-o", LIB, src])
 
 
-def wino_f(w, tile):
+def wino_f(w, tile, quad_order=False):
     """U = G g G^T in float64 -> the kernel's layout U4[p / 4][s][kb][lane][p % 4] (torch_eval.cpp: wino_transform)."""
     if tile == 4:
         G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
@@ -33,8 +33,8 @@ def wino_f(w, tile):
     nq = (n * n + 3) // 4
     out = np.zeros((nq, 16, 4, 64, 4), np.float32)
     k, c, p = np.meshgrid(np.arange(64), np.arange(64), np.arange(n * n), indexing="ij")
-    s = 4 * (c >> 4) + (c & 3)
-    lane = ((c >> 2) & 3) * 16 + (k & 15)
+    s = (c >> 2) if quad_order else 4 * (c >> 4) + (c & 3)              # layout T: a K step is one channel quad
+    lane = ((c & 3) if quad_order else ((c >> 2) & 3)) * 16 + (k & 15)
     out[p >> 2, s, k >> 4, lane, p & 3] = U[k, c, p]
     return out.reshape(-1)
 
@@ -44,10 +44,12 @@ def main():
     ap.add_argument("--game", default="go9")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--layout", default="t", choices=["t", "nchw"], help="t = layout T (the product path), nchw = the round-2 form")
     a = ap.parse_args()
     build()
     L = C.CDLL(LIB)
     L.sprl_wino_conv64_nchw_tiled.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
+    L.sprl_wino_conv64_t.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
     H = W = 9 if a.game == "go9" else 19
     B = a.batch or (8192 if a.game == "go9" else 2048)
     tile = a.tile or L.sprl_wino_nchw_tile(H, W)
@@ -61,19 +63,31 @@ def main():
 
     x, res, y = act(), act(), act()
     w = torch.randn(64, 64, 3, 3) * 0.06
-    u = torch.from_numpy(wino_f(w.numpy(), tile)).cuda()
+    lay_t = a.layout == "t"
+    u = torch.from_numpy(wino_f(w.numpy(), tile, lay_t)).cuda()
     sc, sh = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.3
+    if lay_t:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_cnn import from_layout_t, to_layout_t
+        xt, rest = to_layout_t(x, tile), to_layout_t(res, tile)
+        yt = torch.zeros_like(xt)
 
     def run(with_res=True):
+        if lay_t:
+            return L.sprl_wino_conv64_t(xt.data_ptr(), u.data_ptr(), sc.data_ptr(), sh.data_ptr(), rest.data_ptr() if with_res else None,
+                                        yt.data_ptr(), B, H, W, 1, tile, None, None)
         return L.sprl_wino_conv64_nchw_tiled(x.data_ptr(), u.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr() if with_res else None,
                                              y.data_ptr(), B, H, W, 1, tile, None, None)
 
     assert L.sprl_wino_lab_set_dbg(0) == 0 and run() == 0
     torch.cuda.synchronize()
     nb = min(B, 64)
+    if lay_t:
+        y = from_layout_t(yt, tile, H, W)
     want = torch.relu(torch.nn.functional.conv2d(x[:nb].double(), w.cuda().double(), padding=1) * sc.double().view(1, -1, 1, 1)
                       + sh.double().view(1, -1, 1, 1) + res[:nb].double())
-    print(f"{a.game}: {B} boards, F({tile}x{tile},3x3); max |err| vs float64 conv2d on {nb} boards: {(y[:nb].double() - want).abs().max().item():.2e}")
+    print(f"{a.game}: {B} boards, F({tile}x{tile},3x3), {'layout T' if lay_t else 'NCHW'}; max |err| vs float64 conv2d on {nb} boards: {(y[:nb].double() - want).abs().max().item():.2e}")
     tiles = ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
     flop = 2.0 * B * tiles * (tile + 2) ** 2 * 64 * 64
 
