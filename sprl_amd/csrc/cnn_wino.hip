@@ -350,6 +350,9 @@ constexpr unsigned SLACK_G = 32;                      // bytes that must be read
 
 // tools/nchw_lab.py builds this file with -DSPRL_WINO_LAB: a run-time mask switches stages of the any-board kernel off so that
 // their cost can be read from the launch time (results are then wrong).  Never defined in the product build.
+#ifndef SPRL_WINO_DEEP4
+#define SPRL_WINO_DEEP4 0                             // 1: the F(4x4) layout-T kernel also keeps two activation chunks in flight
+#endif
 #ifdef SPRL_WINO_LAB
 __constant__ int wino_lab_dbg;
 #define LAB_OFF(bit) (wino_lab_dbg & (1 << (bit)))
@@ -520,8 +523,14 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         const bool ok = LAY && pc < NP && t_n >= 0 && R >= 0 && R < H && Cc >= 0 && Cc < W;
         ld_toff[e] = ok ? (((t_n * 16 + ld_quad) * MC + (R % M) * M + Cc % M) * TPB + (R / M) * TX + Cc / M) * 16 : OOB;
     }
-    float pre[LAY ? 4 * NPC : NLD];
-    auto gload = [&](int chunk) {
+    // DEEP (layout T, F(3x3,3x3)): a phase of this tiling is only 50 MFMAs per wave (0.7 us), shorter than a trip to HBM, and
+    // tools/nchw_lab.py showed the kernel waiting on its own prefetches (with the MFMA loop removed it lost only 28 % of its
+    // time).  There are registers to spare at 100 accumulators, so the activation chunks are requested TWO phases ahead (two
+    // register sets, phases unrolled in pairs) and the filter quads two K steps ahead (two rings).
+    constexpr bool DEEP = LAY == 1 && M == 3;         // filter rings two K steps deep
+    constexpr bool DEEP_ACT = LAY == 1 && (M == 3 || SPRL_WINO_DEEP4);      // activation chunks two phases deep
+    float pre0[LAY ? 4 * NPC : NLD], pre1[DEEP_ACT ? 4 * NPC : 1];
+    auto gload = [&](int chunk, float* pre) {
         if (LAB_OFF(0)) return;                        // lab: no activation loads
         if constexpr (LAY == 1) {
 #pragma unroll
@@ -546,7 +555,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
             }
         }
     };
-    auto lstore = [&](float* buf) {
+    auto lstore = [&](float* buf, const float* pre) {
         if (LAB_OFF(1)) return;                        // lab: no patch stores to LDS
         if constexpr (LAY == 1) {
 #pragma unroll
@@ -640,11 +649,13 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         }
     };
     const f4* ua = (const f4*)u + kb * 64 + lane;
-    f4 a[NQ];
-    auto aload = [&](int s, int k) { a[k] = ua[(size_t)k * (16 * 4 * 64) + s * 256]; };
-    // one K step (group of 4 input channels): NP MFMAs; FIRST: the accumulators start from the constant-zero C operand
-    auto kstep = [&](const float* vg, int s, auto first) {
+    f4 a0[NQ], a1[DEEP ? NQ : 1];                     // filter quads of the even / odd K steps (one ring unless DEEP)
+    auto aload = [&](int s, int k, f4* a) { a[k] = ua[(size_t)k * (16 * 4 * 64) + s * 256]; };
+    // one K step (group of 4 input channels): NP MFMAs from ring `a`; FIRST: the accumulators start from the constant-zero C
+    // operand; behind each quad's MFMAs the quad of K step s + AHEAD is requested into the same ring
+    auto kstep = [&](const float* vg, int s, auto first, f4* a) {
         constexpr bool FIRST = decltype(first)::value;
+        constexpr int AHEAD = DEEP ? 2 : 1;
         if (!FIRST && LAB_OFF(3)) return;              // lab: only the first K step (no MFMA loop)
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
@@ -656,36 +667,48 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
                     else acc[k * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][q], b, acc[k * 4 + q], 0, 0, 0);
                 }
             }
-            if (s + 1 < 16) aload(s + 1, k);
+            if (s + AHEAD < 16) aload(s + AHEAD, k, a);
         }
     };
     // rotated by one K step like the 8x8 kernel's loop: K step 0 runs before the loop, an iteration is {K step 2c+1, V(c+1),
-    // chunk c+2 to LDS, request chunk c+3, barrier, K step 2c+2}
-    auto phase = [&](int c) {
+    // chunk c+2 to LDS, request chunk c+3 (DEEP: c+4), barrier, K step 2c+2}
+    auto phase = [&](int c, float* pre) {
         const float* vs = v_buf + (c & 1) * 2 * VG;
-        kstep(vs + VG, 2 * c + 1, std::false_type{});
+        kstep(vs + VG, 2 * c + 1, std::false_type{}, DEEP ? a1 : a0);
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < 8) produce(c + 1);
         if (c + 2 < 8) {
-            lstore(in_buf + (c & 1) * IN_BUF);
-            if (c + 3 < 8) gload(c + 3);
+            lstore(in_buf + (c & 1) * IN_BUF, pre);
+            if (c + (DEEP_ACT ? 4 : 3) < 8) gload(c + (DEEP_ACT ? 4 : 3), pre);
         }
         __syncthreads();
-        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * VG, 2 * c + 2, std::false_type{});
+        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * VG, 2 * c + 2, std::false_type{}, a0);
     };
 
-    gload(0);
-    lstore(in_buf);
-    gload(1);
+    gload(0, pre0);
+    lstore(in_buf, pre0);
+    gload(1, pre0);
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) aload(0, k);
-    lstore(in_buf + IN_BUF);
-    gload(2);
+    for (int k = 0; k < NQ; ++k) aload(0, k, a0);
+    if (DEEP) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) aload(1, k, a1);
+    }
+    lstore(in_buf + IN_BUF, pre0);
+    gload(2, pre0);
+    if (DEEP_ACT) gload(3, pre1);
     __syncthreads();
     produce(0);
     __syncthreads();
-    kstep(v_buf, 0, std::true_type{});
-    for (int c = 0; c < 8; ++c) phase(c);
+    kstep(v_buf, 0, std::true_type{}, a0);
+    if constexpr (DEEP_ACT) {
+        for (int c = 0; c < 8; c += 2) {              // chunk c + 2 waits in pre0, chunk c + 3 in pre1
+            phase(c, pre0);
+            phase(c + 1, pre1);
+        }
+    } else {
+        for (int c = 0; c < 8; ++c) phase(c, pre0);
+    }
 
     if constexpr (LAY == 1) {
         // ---- layout T: inverse transform per row band, the four channels of a cell leave as one 16-byte vector ----
@@ -853,7 +876,8 @@ static int launch_any_board(const float* x, const float* u, const float* scale, 
     const dim3 grid((unsigned)((tiles + 15) / 16)), block(NTHR2);
     // F(3x3): 50 KB of LDS per workgroup, so three fit a CU if the kernel is held to 168 registers (11 of them then spill);
     // SPRL_WINO_F3_OCC=2 selects the two-per-CU build without spills (measured: DESIGN.md section 5)
-    static const int f3_occ = getenv("SPRL_WINO_F3_OCC") ? atoi(getenv("SPRL_WINO_F3_OCC")) : 3;
+    // (layout T with its two-phase-deep prefetch uses the registers of the two-per-CU build)
+    const int f3_occ = getenv("SPRL_WINO_F3_OCC") ? atoi(getenv("SPRL_WINO_F3_OCC")) : (layout_t ? 2 : 3);
     // RES = 0: the first convolution of a residual block has no residual input - no loads, no adds for it
 #define SPRL_LAUNCH_NCHW(MM, OO, LL)                                                                                                      \
     do {                                                                                                                                  \

@@ -45,9 +45,11 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--layout", default="t", choices=["t", "nchw"], help="t = layout T (the product path), nchw = the round-2 form")
+    ap.add_argument("--lib", default=None, help="another lab build of cnn_wino.hip (e.g. -DSPRL_WINO_DEEP4=1)")
     a = ap.parse_args()
-    build()
-    L = C.CDLL(LIB)
+    if not a.lib:
+        build()
+    L = C.CDLL(a.lib or LIB)
     L.sprl_wino_conv64_nchw_tiled.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
     L.sprl_wino_conv64_t.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
     H = W = 9 if a.game == "go9" else 19
