@@ -135,11 +135,13 @@ GAMES = {
                          label="Connect Four 6x7", sym="mirror", noise="Dirichlet(0.25,0.5)", mask_bytes=8, board_bytes=42),
     "go7": dict(engine="go7", rows=7, cols=7, A=50, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8",
                 label="Go 7x7", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=8, board_bytes=49),
-    "go9": dict(engine="go9", rows=9, cols=9, A=82, planes=17, concurrent=1024, traversals=1600, blocks=6, bq="16/8",
+    # resident games (round 3): 2048 for 9x9 / 1024 for 19x19 - the wide tree kernel now keeps 4-8 waves per CU resident (its
+    # position history left LDS), and larger network batches fill the any-board convolution better (profiles/r03l_bench_go*.json)
+    "go9": dict(engine="go9", rows=9, cols=9, A=82, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8",
                 label="Go 9x9", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=11, board_bytes=81, populations=2),
     # config 5 names a resign threshold: on by default for this game (with random-init weights the decision is noise and games
     # end after ~min-ply moves; without it every game runs to the 722-ply cap, ~20 min per step)
-    "go19": dict(engine="go19", rows=19, cols=19, A=362, planes=17, concurrent=256, traversals=1600, blocks=6, bq="16/8",
+    "go19": dict(engine="go19", rows=19, cols=19, A=362, planes=17, concurrent=1024, traversals=1600, blocks=6, bq="16/8",
                  label="Go 19x19", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=46, board_bytes=361,
                  resign_threshold=0.05, resign_min_ply=60, populations=2),
 }

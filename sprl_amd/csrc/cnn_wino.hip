@@ -210,6 +210,9 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // The phase loop is rotated by one K step: K step 0 runs before the loop (it is the one that defines the accumulators), an
     // iteration is then {chunk c+2 to LDS, K step 2c+1, V(c+1), barrier, K step 2c+2}.  Same order of operations as
     // {K step 2c, ..., K step 2c+1, V(c+1), barrier} per phase, only the loop boundary sits elsewhere.
+    // (Two activation chunks in flight - a second register set, the phases unrolled in pairs, as the F(3x3) any-board kernel does -
+    // were measured here in round 3 and dropped: at 144 accumulators the pair of phases spills 42 registers, 210.5 -> 248.1 us,
+    // profiles/r03m_wino_lab_two_chunks_in_flight.log.)
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * V_G2;
         if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
