@@ -890,6 +890,10 @@ static int launch_any_board(const float* x, const float* u, const float* scale, 
             hipLaunchKernelGGL((wino_conv64_nchw_kernel<MM, OO, 0, LL>), grid, block, 0, (hipStream_t)stream, x, u, scale, shift, res, y, batch, H, W, relu, batch_dev); \
     } while (0)
     if (layout_t) {
+#if SPRL_WINO_DEEP4
+        if (tile == 4 && getenv("SPRL_WINO_F4_OCC") && atoi(getenv("SPRL_WINO_F4_OCC")) == 1) SPRL_LAUNCH_NCHW(4, 1, 1);   // lab: one workgroup per CU, 512 registers
+        else
+#endif
         if (tile == 4) SPRL_LAUNCH_NCHW(4, 2, 1);
         else if (f3_occ == 2) SPRL_LAUNCH_NCHW(3, 2, 1);
         else SPRL_LAUNCH_NCHW(3, 3, 1);

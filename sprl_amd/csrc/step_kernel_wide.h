@@ -48,6 +48,12 @@ struct WaveLdsW {
     uint32_t xu[G::STRIPS * 64];
     uint32_t xl[G::STRIPS * 64];              // liberties per group label
     uint32_t xs[G::STRIPS * 64][2];           // label form: signature (lo, hi) of the stones of each opponent group in atari
+    // Bloom filter (two hashes, <= 5 % of the bits set) over the signatures of the REAL game's positions [0, ply]: they do not
+    // change during a search, and almost no candidate move repeats one of them - a candidate walks the signature list of the
+    // real game only on a filter hit and always the few positions of the current descent.  Round 2 scanned all of them for every
+    // empty point of every created node (ply + depth reads per point: the largest part of a late-game 9x9 round).
+    static constexpr int BLOOM_BITS = G::HIST_CAP <= 128 ? 4096 : (G::HIST_CAP <= 256 ? 8192 : 32768);
+    uint32_t bloom[BLOOM_BITS / 32];
     Bits<G::WORDS> xg[G::STRIPS <= 2 ? G::STRIPS * 64 : 1];    // flood form (boards up to two strips): stone mask per group
     uint32_t fcache[SPRL_FCACHE];             // recycled node ids ready for reuse (GameCtl::fcache while the slot runs)
 };
@@ -67,6 +73,34 @@ SPRL_DEV uint64_t pos_sig(const Bits<W>& a, const Bits<W>& b) {
     }
     return s;
 }
+// the two Bloom-filter bit positions of a signature (multiplicative hashes: a signature is a folded bit board, positions that
+// differ in one stone differ in one bit of it, so bit slices of the signature itself would collide for exactly the related
+// positions a game consists of)
+template <class G>
+SPRL_DEV void bloom_bits(uint64_t sg, uint32_t& b0, uint32_t& b1) {
+    constexpr int LOG = WaveLdsW<G>::BLOOM_BITS == 4096 ? 12 : (WaveLdsW<G>::BLOOM_BITS == 8192 ? 13 : 15);
+    b0 = (uint32_t)((sg * 0x9E3779B97F4A7C15ull) >> (64 - LOG));
+    b1 = (uint32_t)((sg * 0xC2B2AE3D27D4EB4Full) >> (64 - LOG));
+}
+template <class G>
+SPRL_DEV void bloom_add(WaveLdsW<G>* lds, uint64_t sg) {             // any number of lanes, each with its own signature
+    uint32_t b0, b1;
+    bloom_bits<G>(sg, b0, b1);
+    wv::atomic_or_u32(&lds->bloom[b0 >> 5], 1u << (b0 & 31));
+    wv::atomic_or_u32(&lds->bloom[b1 >> 5], 1u << (b1 & 31));
+}
+template <class G>
+SPRL_DEV bool bloom_hit(const WaveLdsW<G>* lds, uint64_t sg) {
+    uint32_t b0, b1;
+    bloom_bits<G>(sg, b0, b1);
+    return ((lds->bloom[b0 >> 5] >> (b0 & 31)) & (lds->bloom[b1 >> 5] >> (b1 & 31)) & 1u) != 0;
+}
+template <class G>
+SPRL_DEV void bloom_clear(WaveLdsW<G>* lds) {                         // all lanes
+    for (int i = wv::lane(); i < WaveLdsW<G>::BLOOM_BITS / 32; i += 64) lds->bloom[i] = 0u;
+    wv::sync();
+}
+
 // contribution of one stone at point a of Player `plane` to pos_sig
 SPRL_DEV uint64_t stone_sig(int a, int plane) {
     const int w = a >> 6, r = (11 * w + (plane ? 33 : 1)) & 63;
@@ -236,7 +270,8 @@ SPRL_DEV PosW<G::WORDS> pos_of(const NodeHdrW<G::WORDS>& h) {
 // liberties, neighbour inspection through the LDS exchange, exact positional-superko compare with the ancestors.
 // Small boards (up to two strips): every stone lane flood-fills its own group as a bit set - fewer, wider steps.
 template <class G>
-SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, const Bits<G::WORDS>* ring, int n_hist) {
+SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, const Bits<G::WORDS>* ring, int n_hist, int n_game) {
+    // positions [0, n_game) of the line are the real game's (Bloom filter), [n_game, n_hist) the current descent's
     using BB = Bits<G::WORDS>;
     const int l = wv::lane();
     const BB own = c.player ? c.p1 : c.p0, opp = c.player ? c.p0 : c.p1;
@@ -285,8 +320,11 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>
             const BB np0 = c.player ? nopp : nown, np1 = c.player ? nown : nopp;
             bool repeat = false;
             const uint64_t sg = pos_sig<G::WORDS>(np0, np1);
-            for (int i = 0; i < n_hist; ++i)
+            for (int i = n_game; i < n_hist; ++i)
                 if (lds->hsig[i] == sg) repeat |= (ring[2 * i] == np0) && (ring[2 * i + 1] == np1);
+            if (has_libs && bloom_hit<G>(lds, sg))
+                for (int i = 0; i < n_game; ++i)
+                    if (lds->hsig[i] == sg) repeat |= (ring[2 * i] == np0) && (ring[2 * i + 1] == np1);
             ok = has_libs && !repeat;
         }
         const uint64_t m = wv::ballot(ok);
@@ -298,11 +336,12 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask_flood(const PosW<G::WORDS>& c, WaveLdsW<G>
 // Large boards: per-lane bit sets would need 2 x STRIPS x WORDS registers and one wide dilate per step; groups are
 // labelled instead (measured at 19x19: 3.6-4.9x faster than the flood form; at 9x9 the flood form is 25 % faster).
 template <class G>
-SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, const Bits<G::WORDS>* ring, int n_hist, int form) {
+SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds, const Bits<G::WORDS>* ring, int n_hist, int n_game,
+                                      int form) {
     // form: 0 = by board size (flood up to two strips, labels above), 1 = labels, 2 = flood (tests run both forms on the boards
     // of up to two strips; the per-group stone masks of the flood form have no room in LDS on larger boards)
     if constexpr (G::STRIPS <= 2) {
-        if (form == 2 || form == 0) return go_legal_mask_flood<G>(c, lds, ring, n_hist);
+        if (form == 2 || form == 0) return go_legal_mask_flood<G>(c, lds, ring, n_hist, n_game);
     }
     using BB = Bits<G::WORDS>;
     const int l = wv::lane();
@@ -417,7 +456,9 @@ SPRL_DEV Bits<G::WORDS> go_legal_mask(const PosW<G::WORDS>& c, WaveLdsW<G>* lds,
                 }
             }
             if (has_libs) {
-                for (int i = 0; i < n_hist; ++i) sus |= lds->hsig[i] == sg;
+                for (int i = n_game; i < n_hist; ++i) sus |= lds->hsig[i] == sg;          // the current descent: a few positions
+                if (bloom_hit<G>(lds, sg))                                                  // the real game: only on a filter hit
+                    for (int i = 0; i < n_game; ++i) sus |= lds->hsig[i] == sg;
             }
             ok = has_libs;
         }
@@ -459,7 +500,7 @@ SPRL_DEV void make_child(GameW& g, WaveLdsW<G>* lds, const PosW<G::WORDS>& paren
     Bits<G::WORDS>* ring = (Bits<G::WORDS>*)g.ring;
     if (wv::lane() == 0) hist_put<G>(lds, ring, at, cs.p0, cs.p1);
     wv::wave_fence();                          // the ring entry is read by other lanes (suspect verification, leaf history)
-    if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, ring, at + 1, g.legal_form);
+    if (!cs.terminal) cs.legal = go_legal_mask<G>(cs, lds, ring, at + 1, g.ply + 1 < at + 1 ? g.ply + 1 : at + 1, g.legal_form);
 }
 
 // Dirichlet root noise (UCTNode.hpp:330-347, utils/random.cpp:61-74)
@@ -872,7 +913,11 @@ SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>*
     g.traversals = 0;
     g.n_leaves = 0;
     g.d_created++;
-    if (wv::lane() == 0) hist_put<G>(lds, (Bits<G::WORDS>*)g.ring, 0, s.p0, s.p1);
+    bloom_clear<G>(lds);
+    if (wv::lane() == 0) {
+        hist_put<G>(lds, (Bits<G::WORDS>*)g.ring, 0, s.p0, s.p1);
+        bloom_add<G>(lds, lds->hsig[0]);
+    }
     wv::wave_fence();
 }
 
@@ -994,7 +1039,10 @@ SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* l
     g.ply += 1;
     {
         const NodeHdrW<G::WORDS> nh = load_hdr<G>(node_at<G>(g.abase, c));
-        if (l == 0) hist_put<G>(lds, (Bits<G::WORDS>*)g.ring, g.ply, nh.p0, nh.p1);      // the real game's line grows by one
+        if (l == 0) {                                                                   // the real game's line grows by one
+            hist_put<G>(lds, (Bits<G::WORDS>*)g.ring, g.ply, nh.p0, nh.p1);
+            bloom_add<G>(lds, lds->hsig[g.ply]);
+        }
         wv::wave_fence();
     }
     g.epoch += 1;
@@ -1032,9 +1080,14 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
     g.abase = P.arenas + (size_t)g.arena * (size_t)P.node_cap * G::NODE_BYTES;
     g.ring = (void*)((Bits<G::WORDS>*)P.hist_boards + (size_t)slot * G::HIST_CAP * 2);
     wv::sync();
-    if (g.status == ST_ACTIVE) {               // the signatures of the real game's positions, from the ring
+    if (g.status == ST_ACTIVE) {               // the signatures of the real game's positions, from the ring, and their filter
+        bloom_clear<G>(lds);
         const Bits<G::WORDS>* gh = (const Bits<G::WORDS>*)g.ring;
-        for (int i = wv::lane(); i <= g.ply; i += 64) lds->hsig[i] = pos_sig<G::WORDS>(gh[2 * i], gh[2 * i + 1]);
+        for (int i = wv::lane(); i <= g.ply; i += 64) {
+            const uint64_t sg = pos_sig<G::WORDS>(gh[2 * i], gh[2 * i + 1]);
+            lds->hsig[i] = sg;
+            bloom_add<G>(lds, sg);
+        }
         wv::sync();
     }
     if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);

@@ -64,6 +64,7 @@ template <typename T> static inline T uni(T v) {
 }
 static inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t atomic_xor_u32(uint32_t* p, uint32_t v) { return __atomic_fetch_xor(p, v, __ATOMIC_RELAXED); }
+static inline uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) {
     return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
@@ -127,6 +128,7 @@ SPRL_DEV uint64_t uni(uint64_t v) {
 }
 SPRL_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 SPRL_DEV uint32_t atomic_xor_u32(uint32_t* p, uint32_t v) { return atomicXor(p, v); }
+SPRL_DEV uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 SPRL_DEV unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 SPRL_DEV uint32_t atomic_cas_u32(uint32_t* p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
 SPRL_DEV void atomic_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
