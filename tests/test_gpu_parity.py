@@ -706,13 +706,14 @@ def test_go19_full_budget_with_compaction_and_resign(lib):
     compaction into a spare arena - fires many times per game (games run to the double pass / the 722-ply cap, as in the
     reference); then as the engine runs by default (recycling, default arena of 4 x 1600 + 1024 nodes, no spare
     arenas needed) with the resign extension on."""
-    rec, st = parity.check_case(lib, "go19", 2, concurrent_games=2, num_traversals=1600, node_cap=8000, spare_arenas=2, seed=5,
+    # (one game in this leg: the oracle plays it too, on one host core, and the driver's GPU-test budget is shared with 86 others)
+    rec, st = parity.check_case(lib, "go19", 1, concurrent_games=1, num_traversals=1600, node_cap=8000, spare_arenas=2, seed=5,
                                 no_recycle=1)
     assert rec.cells == 361 and st["compactions"] >= 10 and st["max_nodes_in_arena"] <= 8000
     assert st["traversals"] >= 1600 * st["plies"]
     rec2, st2 = parity.check_case(lib, "go19", 2, concurrent_games=2, num_traversals=1600, spare_arenas=0, seed=6,
                                   resign_threshold=0.02, resign_min_ply=30)
-    assert st2["compactions"] == 0 and st2["nodes_recycled"] > 0.9 * st2["nodes_created"] and st2["plies"] < st["plies"]
+    assert st2["compactions"] == 0 and st2["nodes_recycled"] > 0.9 * st2["nodes_created"] and st2["plies"] < 2 * st["plies"]
     assert st2["max_nodes_in_arena"] <= 4 * 1600 + 1024
 
 
