@@ -80,6 +80,16 @@ struct HeadArgs {
     float* maps_out;        // ReLU'd head maps [batch][3 * H * W]; the FC layers run in sprl_tail_fc (cnn_epilogue.hip)
 };
 
+#ifndef SPRL_WINO_DEEP4
+#define SPRL_WINO_DEEP4 0                             // 1: the F(4x4) layout-T kernel also keeps two activation chunks in flight
+#endif
+#ifdef SPRL_WINO_LAB
+__constant__ int wino_lab_dbg;
+#define LAB_OFF(bit) (wino_lab_dbg & (1 << (bit)))
+#else
+#define LAB_OFF(bit) 0
+#endif
+
 constexpr int NIMG2 = 4, NTHR2 = 256;
 constexpr int CS2 = 449;                 // channel-slot stride for 4 boards (== 1 mod 32)
 constexpr int IN_BUF2 = 8 * CS2;
@@ -153,6 +163,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
         float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
         float wr[3][6];
+        if (LAB_OFF(2)) return;                       // lab: no input transform
         if (wa == 0) {                                // (the wave-uniform branch outside the loop: one scheduling region per role)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -200,10 +211,15 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int p = q4 * 4 + e;
-                if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], vg[p * 64 + lane], (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
-                else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], vg[p * 64 + lane], acc[p], 0, 0, 0);
+#if defined(SPRL_WINO_LAB_BREUSE)                     // lab build: every B operand (LDS read) feeds TWO MFMAs - half the K loop's LDS reads
+                const float bv = vg[(p & ~1) * 64 + lane];
+#else
+                const float bv = vg[p * 64 + lane];
+#endif
+                if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], bv, (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
+                else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], bv, acc[p], 0, 0, 0);
             }
-            if (s + 1 < 16) aload(s + 1, q4);
+            if (s + 1 < 16 && !LAB_OFF(6)) aload(s + 1, q4);     // (lab bit 6: the filter quads are loaded once and reused)
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -247,6 +263,15 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     for (int c = 0; c < 8; ++c) phase(c);             // stays a rolled loop: peeled or fully unrolled forms measured 5 % slower
 
     // ---- inverse transform in registers + epilogue ----
+#ifdef SPRL_WINO_LAB
+    if (LAB_OFF(7)) {                                 // lab: no output stage (one store keeps the accumulators alive)
+        f4 sum = acc[0];
+#pragma unroll
+        for (int q = 1; q < 36; ++q) sum += acc[q];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, sum), ry, ovoff, 0, 2);
+        return;
+    }
+#endif
     if (RES) {
         rload(0);
         rload(1);
@@ -353,15 +378,6 @@ constexpr unsigned SLACK_G = 32;                      // bytes that must be read
 
 // tools/nchw_lab.py builds this file with -DSPRL_WINO_LAB: a run-time mask switches stages of the any-board kernel off so that
 // their cost can be read from the launch time (results are then wrong).  Never defined in the product build.
-#ifndef SPRL_WINO_DEEP4
-#define SPRL_WINO_DEEP4 0                             // 1: the F(4x4) layout-T kernel also keeps two activation chunks in flight
-#endif
-#ifdef SPRL_WINO_LAB
-__constant__ int wino_lab_dbg;
-#define LAB_OFF(bit) (wino_lab_dbg & (1 << (bit)))
-#else
-#define LAB_OFF(bit) 0
-#endif
 
 template <int M>
 struct NchwGeom {
