@@ -111,7 +111,8 @@ int sprl_engine_set_forward(sprl_engine* e, sprl_forward_fn fn, void* user);
  * agents/UCTNetworkAgent.hpp:45-108, interface/play.hpp:22-60).  Game i seeds Random(seed, stream_base + i); agent k
  * moves first in the games with i % 2 == k (Evaluate.cpp:126-130).  Tree options as in Evaluate.cpp:94-112: the
  * caller passes dir_eps 0.25 / dir_alpha 0.1 / add_noise 1 / u_weight in `cfg`; per agent: symmetrisation and
- * InitQ.  `cfg->concurrent_games` game PAIRS of trees are resident at once.  Othello, Connect Four, Go 7x7.
+ * InitQ.  `cfg->concurrent_games` game PAIRS of trees are resident at once.  Every game of the engine (since round 3 also
+ * Go 9x9 / 19x19 through the wide kernel).
  * Outputs (host memory, caller-owned): winners[num_games] (0, 1, -1 = draw; colour, not agent),
  * nplies[num_games], actions[num_games][max_plies] (-1 padded). */
 enum { SPRL_INITQ_PARENT = 0, SPRL_INITQ_ZERO = 1 };

@@ -38,6 +38,13 @@ __global__ void __launch_bounds__(64) match_kernel(EngineParams P) {
 }
 
 template <class G>
+__global__ void __launch_bounds__(64) match_kernel_wide(EngineParams P) {
+    __shared__ sprlw::WaveLdsW<G> lds;
+    const int slot = (int)blockIdx.x;
+    if (slot < P.num_slots) sprlw::step_match<G>(P, slot, &lds);
+}
+
+template <class G>
 __global__ void __launch_bounds__(64) step_kernel_wide(EngineParams P) {
     __shared__ sprlw::WaveLdsW<G> lds;
     const int slot = (int)blockIdx.x;
@@ -212,8 +219,11 @@ int launch_match(int game, const EngineParams& P) {
     if (game == SPRL_GAME_OTHELLO) hipLaunchKernelGGL(match_kernel<Othello>, grid, block, 0, g_stream, P);
     else if (game == SPRL_GAME_GO7) hipLaunchKernelGGL(match_kernel<Go7>, grid, block, 0, g_stream, P);
     else if (game == SPRL_GAME_CONNECT_FOUR) hipLaunchKernelGGL(match_kernel<ConnectFour>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO9) hipLaunchKernelGGL(match_kernel_wide<GoN<9>>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO19) hipLaunchKernelGGL(match_kernel_wide<GoN<19>>, grid, block, 0, g_stream, P);
+    else if (game == SPRL_GAME_GO7W) hipLaunchKernelGGL(match_kernel_wide<GoN<7>>, grid, block, 0, g_stream, P);
     else {
-        g_err = "match play is built for Othello, Connect Four and Go 7x7";
+        g_err = "unknown game";
         return -1;
     }
     return ok(hipGetLastError(), "match_kernel launch") ? 0 : -1;

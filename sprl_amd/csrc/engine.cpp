@@ -849,8 +849,6 @@ int sprl_match_play(const sprl_config* cfg, const sprl_match_agent* agent0, cons
     if (!cfg || !agent0 || !agent1 || !winners || !nplies) return fail(SPRL_E_CONFIG, "null argument");
     if (num_games < 1) return fail(SPRL_E_CONFIG, "num_games must be >= 1");
     if (actions && max_plies < 1) return fail(SPRL_E_CONFIG, "max_plies must be >= 1 when actions are requested");
-    if (cfg->game != SPRL_OTHELLO && cfg->game != SPRL_CONNECT_FOUR && cfg->game != SPRL_GO7)
-        return fail(SPRL_E_CONFIG, "match play is built for Othello, Connect Four and Go 7x7");
     sprl_config c = *cfg;
     const int pairs = c.concurrent_games < num_games ? c.concurrent_games : num_games;
     if (pairs < 1) return fail(SPRL_E_CONFIG, "concurrent_games must be >= 1");
@@ -889,7 +887,7 @@ int sprl_match_play(const sprl_config* cfg, const sprl_match_agent* agent0, cons
     }
     const size_t na = (size_t)num_games * (size_t)P.max_plies;
     bool ok = true;
-    ok = ok && (P.mailbox = (Mailbox*)dev_alloc(e, (size_t)P.num_slots * sizeof(Mailbox)));
+    ok = ok && (P.mailbox = (Mailbox*)dev_alloc(e, 2 * (size_t)P.num_slots * sizeof(Mailbox)));      // two entries per slot (step_match)
     ok = ok && (P.match_actions = (int16_t*)dev_alloc(e, na * sizeof(int16_t)));
     ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
     ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
@@ -909,7 +907,7 @@ int sprl_match_play(const sprl_config* cfg, const sprl_match_agent* agent0, cons
     rc |= be::h2d(P.ctl, ctl.data(), ctl.size() * sizeof(GameCtl));
     rc |= be::h2d(P.arena_used, used.data(), used.size() * sizeof(uint32_t));
     rc |= be::h2d(P.counters, &cn, sizeof(cn));
-    rc |= be::dmemset(P.mailbox, 0, (size_t)P.num_slots * sizeof(Mailbox));
+    rc |= be::dmemset(P.mailbox, 0, 2 * (size_t)P.num_slots * sizeof(Mailbox));
     rc |= be::dmemset(P.match_actions, 0xff, na * sizeof(int16_t));
     rc |= be::dmemset(P.rec_nplies, 0, (size_t)num_games * sizeof(int32_t));
     rc |= be::sync();

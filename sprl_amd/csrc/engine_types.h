@@ -128,7 +128,7 @@ struct EngineParams {
     // match play (Evaluate.cpp): per-agent options, agent = slot & 1, game = slot >> 1
     int32_t m_use_sym[2], m_eval_kind[2], m_init_q_zero[2];
     uint32_t launch_seq;
-    Mailbox* mailbox;       // [num_slots]
+    Mailbox* mailbox;       // [num_slots][2]: entry (game sequence of the pair) & 1
     int16_t* match_actions; // [num_games][max_plies]
     uint8_t* arenas;
     uint32_t* arena_used;   // [num_slots + num_spare] 0 free / 1 used

@@ -1078,7 +1078,10 @@ SPRL_DEV void step_match(const EngineParams& P0, int slot, WaveLds<G>* lds) {
             continue;
         }
         if ((int)g.root_player != (agent ^ (int)(g.game_id & 1u))) {
-            const Mailbox mb = P.mailbox[slot];
+            // two entries per slot, alternating with the pair's game sequence: the side that ended game g may start game g + n
+            // and - if it moves first there - post its first move before the partner has picked up the LAST move of game g
+            // (with few traversals per move a whole search fits into one launch); that move must not be overwritten
+            const Mailbox mb = P.mailbox[2 * slot + (int)((g.game_id / (uint32_t)n) & 1u)];
             wv::sync();
             const uint32_t m_ply1 = (uint32_t)(mb.ply_launch & 0xffffffffull), m_launch = (uint32_t)(mb.ply_launch >> 32);
             if (m_launch != P.launch_seq && m_ply1 == (uint32_t)g.ply + 1u && mb.game == g.game_id) {
@@ -1101,7 +1104,7 @@ SPRL_DEV void step_match(const EngineParams& P0, int slot, WaveLds<G>* lds) {
             advance_root<G>(P, g, slot, lds, action);                  // act (:101)
             g.d_plies++;
             if (l == 0) {
-                Mailbox* mb = P.mailbox + partner;
+                Mailbox* mb = P.mailbox + 2 * partner + (int)((g.game_id / (uint32_t)n) & 1u);
                 mb->game = g.game_id;
                 mb->action = (uint32_t)action;
                 mb->rng_state = g.rng.state;

@@ -755,7 +755,7 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
                 created = true;
                 make_child<G>(g, lds, pos_of<G>(h), a, g.ply + depth, cs);
                 write_new_node<G>(node_at<G>(g.abase, c), cs, a);
-                w_a = h.value;                                               // InitQ::PARENT
+                w_a = P.init_q_zero ? 0.0f : h.value;                        // InitQ::PARENT / ZERO (UCTNode.hpp:258-284)
                 g.d_created++;
                 if (a == WPASS) hp->passChild = c;
                 else if ((a & 63) == l) rowC<G>(np)[a] = (uint16_t)c;
@@ -887,10 +887,19 @@ SPRL_DEV bool compact_arena(const EngineParams& P, GameW& g) {
 }
 
 template <class G>
+SPRL_DEV void init_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds, uint32_t gid);
+
+template <class G>
 SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds) {
     uint32_t gid = 0;
     if (wv::lane() == 0) gid = wv::atomic_add_u32(&P.counters->next_game, 1u);
     gid = wv::bcast_u32(gid, 0);
+    init_game<G>(P, g, slot, lds, gid);
+}
+
+// game `gid` starts in this slot (self-play: the next game of the global counter; match play: the pair's next game)
+template <class G>
+SPRL_DEV void init_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds, uint32_t gid) {
     if (gid >= (uint32_t)P.num_games) {
         g.status = ST_IDLE;
         return;
@@ -920,6 +929,9 @@ SPRL_DEV void start_game(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>*
     }
     wv::wave_fence();
 }
+
+template <class G>
+SPRL_DEV void advance_root(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds, int action);
 
 // SelfPlay.hpp:110-148
 template <class G>
@@ -1000,6 +1012,20 @@ SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* l
         const uint64_t ge = wv::ballot(st * 64 + l < G::NA && !(cdf[st] < x));
         if (action == WPASS && ge) action = st * 64 + wv::ctz64(ge);
     }
+    advance_root<G>(P, g, slot, lds, action);
+    g.d_plies++;
+    return 0;
+}
+
+// UCTTree::advanceDecision (uct/UCTTree.hpp:197-210): the decision node moves along `action` (self-play: the sampled move;
+// match play: the agent's own move or the opponent's), its edge statistics become the new root's own N / W (Q6), the epoch
+// bump turns every active node gray, the old root goes on the reclaim stack
+template <class G>
+SPRL_DEV void advance_root(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds, int action) {
+    const int l = wv::lane();
+    uint8_t* np = node_at<G>(g.abase, g.root);
+    const NodeHdrW<G::WORDS> h = load_hdr<G>(np);
+    const bool expanded = h.exp_epoch == g.epoch;      // rows of a node that is not active hold no valid statistics
     uint32_t c = SPRL_NONE16;
     float n_a = 0.0f, w_a = 0.0f;
     if (action == WPASS) {
@@ -1010,17 +1036,20 @@ SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* l
         const int sa = action >> 6, la = action & 63;
         for (int st = 0; st < WS; ++st) {
             const uint32_t cc = wv::bcast_u32((uint32_t)rowC<G>(np)[st * 64 + l], la);
-            const float nn = wv::bcast_f32(visits[st], la);
+            const float nn = wv::bcast_f32(rowN<G>(np)[st * 64 + l], la);
             const float ww = wv::bcast_f32(rowW<G>(np)[st * 64 + l], la);
             if (st == sa) { c = cc; n_a = nn; w_a = ww; }
         }
     }
+    if (!expanded) { n_a = 0.0f; w_a = 0.0f; }
+    wv::sync();
     if (c == SPRL_NONE16) {
         PosW<G::WORDS> cs;
         make_child<G>(g, lds, pos_of<G>(h), action, g.ply + 1, cs);
         c = alloc_node<G>(g, lds);
         write_new_node<G>(node_at<G>(g.abase, c), cs, action);
-        w_a = (h.flags & F_EVAL) ? h.value : 0.0f;
+        g.d_created++;
+        w_a = (!P.init_q_zero && (h.flags & F_EVAL)) ? h.value : 0.0f;
     } else if (P.recycle) {                   // pruneChildrenExcept: cut the edge to the kept child, the rest is garbage
         if (action == WPASS) hdr_of<G>(np)->passChild = SPRL_NONE16;
         else if ((action & 63) == l) rowC<G>(np)[action] = (uint16_t)SPRL_NONE16;
@@ -1047,16 +1076,11 @@ SPRL_DEV int play_move(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* l
     }
     g.epoch += 1;
     g.traversals = 0;
-    g.d_plies++;
-    return 0;
 }
 
+// the slot's control block -> the wave's working state (and the line's signatures + their filter back into LDS)
 template <class G>
-SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
-    GameCtl* ctl = P.ctl + slot;
-    GameW g;
-    g.status = ctl->status;
-    if (g.status == ST_IDLE || g.status == ST_ERROR) return;
+SPRL_DEV void game_load(const EngineParams& P, int slot, GameCtl* ctl, WaveLdsW<G>* lds, GameW& g) {
     g.rng.state = ctl->rng_state;
     g.rng.inc = ctl->rng_inc;
     g.game_id = ctl->game_id;
@@ -1090,42 +1114,10 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
         }
         wv::sync();
     }
-    if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);
+}
 
-    int round = 0;
-    while (g.status == ST_ACTIVE) {
-        if (g.n_leaves > 0) {
-            if (P.eval_kind == EVAL_NETWORK && round > 0) break;
-            finish_leaves<G>(P, g, slot, ctl, lds);
-        }
-        bool idle = false;
-        while (g.traversals >= P.num_traversals) {
-            const int resigned = play_move<G>(P, g, slot, lds);
-            if (g.status != ST_ACTIVE) break;
-            const NodeHdrW<G::WORDS> rh = load_hdr<G>(node_at<G>(g.abase, g.root));
-            if (resigned || (rh.flags & F_TERMINAL)) {
-                P.rec_nplies[g.game_id] = resigned ? g.ply + 1 : g.ply;
-                P.rec_winner[g.game_id] = resigned ? (int8_t)(resigned - 1) : rh.winner;
-                g.d_games++;
-                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
-                start_game<G>(P, g, slot, lds);
-                if (g.status != ST_ACTIVE) { idle = true; break; }
-            }
-        }
-        if (idle || g.status != ST_ACTIVE) break;
-        {   // `need` nodes before a search batch: recycled ids, then fresh arena space, then (rarely) a compaction
-            const uint32_t need = (uint32_t)P.max_batch + 1u;
-            if (P.recycle && g.fc_n < need && g.rstack_n > 0) reclaim_refill<G>(P, g, slot, lds);
-            if (g.fc_n + ((uint32_t)P.node_cap - g.n_alloc) < need) {
-                if (!compact_arena<G>(P, g)) break;
-                if ((uint32_t)P.node_cap - g.n_alloc < need) { raise_error(P, g, ERR_ARENA_FULL); break; }
-            }
-        }
-        select_batch<G>(P, g, slot, ctl, lds);
-        ++round;
-        if (P.eval_kind != EVAL_NETWORK && round >= P.rounds) break;
-    }
-
+template <class G>
+SPRL_DEV void game_store(GameCtl* ctl, const GameW& g, WaveLdsW<G>* lds) {
     ctl->status = g.status;
     ctl->rng_state = g.rng.state;
     ctl->rng_inc = g.rng.inc;
@@ -1160,7 +1152,148 @@ SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
         t.nodes_recycled += g.d_recycled;
         if (g.hi_alloc > t.max_alloc) t.max_alloc = g.hi_alloc;
     }
+}
+
+// `need` nodes before a search batch: recycled ids, then fresh arena space, then (rarely) a compaction
+template <class G>
+SPRL_DEV bool ensure_nodes(const EngineParams& P, GameW& g, int slot, WaveLdsW<G>* lds, uint32_t need) {
+    if (P.recycle && g.fc_n < need && g.rstack_n > 0) reclaim_refill<G>(P, g, slot, lds);
+    if (g.fc_n + ((uint32_t)P.node_cap - g.n_alloc) < need) {
+        if (!compact_arena<G>(P, g)) return false;
+        if ((uint32_t)P.node_cap - g.n_alloc < need) { raise_error(P, g, ERR_ARENA_FULL); return false; }
+    }
+    return true;
+}
+
+template <class G>
+SPRL_DEV void step_game(const EngineParams& P, int slot, WaveLdsW<G>* lds) {
+    GameCtl* ctl = P.ctl + slot;
+    GameW g;
+    g.status = ctl->status;
+    if (g.status == ST_IDLE || g.status == ST_ERROR) return;
+    game_load<G>(P, slot, ctl, lds, g);
+    if (g.status == ST_FRESH) start_game<G>(P, g, slot, lds);
+
+    int round = 0;
+    while (g.status == ST_ACTIVE) {
+        if (g.n_leaves > 0) {
+            if (P.eval_kind == EVAL_NETWORK && round > 0) break;
+            finish_leaves<G>(P, g, slot, ctl, lds);
+        }
+        bool idle = false;
+        while (g.traversals >= P.num_traversals) {
+            const int resigned = play_move<G>(P, g, slot, lds);
+            if (g.status != ST_ACTIVE) break;
+            const NodeHdrW<G::WORDS> rh = load_hdr<G>(node_at<G>(g.abase, g.root));
+            if (resigned || (rh.flags & F_TERMINAL)) {
+                P.rec_nplies[g.game_id] = resigned ? g.ply + 1 : g.ply;
+                P.rec_winner[g.game_id] = resigned ? (int8_t)(resigned - 1) : rh.winner;
+                g.d_games++;
+                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
+                start_game<G>(P, g, slot, lds);
+                if (g.status != ST_ACTIVE) { idle = true; break; }
+            }
+        }
+        if (idle || g.status != ST_ACTIVE) break;
+        if (!ensure_nodes<G>(P, g, slot, lds, (uint32_t)P.max_batch + 1u)) break;
+        select_batch<G>(P, g, slot, ctl, lds);
+        ++round;
+        if (P.eval_kind != EVAL_NETWORK && round >= P.rounds) break;
+    }
+
+    game_store<G>(ctl, g, lds);
     P.leaf_count[slot] = g.status == ST_ACTIVE ? (uint32_t)g.n_leaves : 0u;
+    if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
+}
+
+// Match play on the wide boards (Evaluate.cpp:104-170, agents/UCTNetworkAgent.hpp, interface/play.hpp:22-60): the same protocol
+// as step_kernel.h: step_match - game g is played by TWO trees in slots (pair, pair + n), only the side to move searches, its
+// move (the first maximum of the visit counts, UCTNetworkAgent.hpp:88-89) is applied to its own tree and posted with the game's
+// RNG state to the partner's mailbox, which applies it as opponentAct in a LATER launch.
+template <class G>
+SPRL_DEV void step_match(const EngineParams& P0, int slot, WaveLdsW<G>* lds) {
+    const int n = P0.num_slots >> 1;
+    const int agent = slot >= n ? 1 : 0;
+    const int partner = agent ? slot - n : slot + n;
+    EngineParams P = P0;
+    P.use_sym = P0.m_use_sym[agent];
+    P.eval_kind = P0.m_eval_kind[agent];
+    P.init_q_zero = P0.m_init_q_zero[agent];
+    GameCtl* ctl = P.ctl + slot;
+    GameW g;
+    g.status = ctl->status;
+    if (g.status == ST_IDLE || g.status == ST_ERROR) {
+        P.leaf_count[slot] = 0u;
+        return;
+    }
+    game_load<G>(P, slot, ctl, lds, g);
+    if (g.status == ST_FRESH) init_game<G>(P, g, slot, lds, (uint32_t)(slot - agent * n));
+
+    int round = 0;
+    while (round < P.rounds && g.status == ST_ACTIVE) {
+        if (g.n_leaves > 0) finish_leaves<G>(P, g, slot, ctl, lds);
+        const NodeHdrW<G::WORDS> rh = load_hdr<G>(node_at<G>(g.abase, g.root));
+        if (rh.flags & F_TERMINAL) {                               // play.hpp:34
+            if (agent == 0) {
+                P.rec_nplies[g.game_id] = g.ply;
+                P.rec_winner[g.game_id] = rh.winner;
+                if (wv::lane() == 0) wv::atomic_add_u32(&P.counters->games_done, 1u);
+            }
+            g.d_games++;
+            init_game<G>(P, g, slot, lds, g.game_id + (uint32_t)n);   // this pair's next game, if any
+            continue;
+        }
+        if ((int)g.root_player != (agent ^ (int)(g.game_id & 1u))) {
+            // two entries per slot, alternating with the pair's game sequence: the side that ended game g may start game g + n
+            // and - if it moves first there - post its first move before the partner has picked up the LAST move of game g
+            // (with few traversals per move a whole search fits into one launch); that move must not be overwritten
+            const Mailbox mb = P.mailbox[2 * slot + (int)((g.game_id / (uint32_t)n) & 1u)];
+            wv::sync();
+            const uint32_t m_ply1 = (uint32_t)(mb.ply_launch & 0xffffffffull), m_launch = (uint32_t)(mb.ply_launch >> 32);
+            if (m_launch != P.launch_seq && m_ply1 == (uint32_t)g.ply + 1u && mb.game == g.game_id) {
+                advance_root<G>(P, g, slot, lds, (int)mb.action);          // opponentAct (UCTNetworkAgent.hpp:106-108)
+                g.rng.state = mb.rng_state;
+                continue;
+            }
+            break;                                                  // the partner is still thinking
+        }
+        if (g.traversals >= P.num_traversals) {
+            uint8_t* np = node_at<G>(g.abase, g.root);
+            const int l = wv::lane();
+            float top = -1.0f;
+            float visits[WS];
+            for (int st = 0; st < WS; ++st) {
+                visits[st] = st * 64 + l < G::NA ? rowN<G>(np)[st * 64 + l] : -1.0f;
+                const float m = wv::fmax_all(visits[st]);
+                top = m > top ? m : top;
+            }
+            int action = -1;                                        // std::max_element: the FIRST maximum in index order
+            for (int st = 0; st < WS; ++st) {
+                const uint64_t eq = wv::ballot(visits[st] == top);
+                if (action < 0 && eq) action = st * 64 + wv::ctz64(eq);
+            }
+            if (rh.passN > top) action = WPASS;
+            wv::sync();
+            if (g.ply < P.max_plies) P.match_actions[(size_t)g.game_id * (size_t)P.max_plies + (size_t)g.ply] = (int16_t)action;
+            const uint32_t ply1 = (uint32_t)g.ply + 1u;
+            advance_root<G>(P, g, slot, lds, action);                  // act (:101)
+            g.d_plies++;
+            if (l == 0) {
+                Mailbox* mb = P.mailbox + 2 * partner + (int)((g.game_id / (uint32_t)n) & 1u);
+                mb->game = g.game_id;
+                mb->action = (uint32_t)action;
+                mb->rng_state = g.rng.state;
+                mb->ply_launch = (uint64_t)ply1 | ((uint64_t)P.launch_seq << 32);
+            }
+            continue;
+        }
+        if (!ensure_nodes<G>(P, g, slot, lds, (uint32_t)P.max_batch + 2u)) break;
+        select_batch<G>(P, g, slot, ctl, lds);
+        ++round;
+    }
+
+    game_store<G>(ctl, g, lds);
+    P.leaf_count[slot] = (g.status == ST_ACTIVE && P.eval_kind == EVAL_NETWORK) ? (uint32_t)g.n_leaves : 0u;
     if (g.status == ST_ACTIVE && wv::lane() == 0) wv::atomic_add_u32(&P.counters->active_slots, 1u);
 }
 

@@ -33,6 +33,12 @@ void block_entry_match(void* arg, int block) {
     sprl::step_match<G>(*P, block, reinterpret_cast<sprl::WaveLds<G>*>(tl_lds));
 }
 template <class G>
+void block_entry_match_wide(void* arg, int block) {
+    const EngineParams* P = static_cast<const EngineParams*>(arg);
+    sprlw::step_match<G>(*P, block, reinterpret_cast<sprlw::WaveLdsW<G>*>(tl_lds));
+}
+
+template <class G>
 void block_entry_wide(void* arg, int block) {
     const EngineParams* P = (const EngineParams*)arg;
     static_assert(sizeof(sprlw::WaveLdsW<G>) <= sizeof(tl_lds), "emulated LDS too small");
@@ -72,6 +78,9 @@ int launch_match(int game, const EngineParams& P) {
     if (game == SPRL_GAME_OTHELLO) emu::launch(block_entry_match<Othello>, &copy, P.num_slots);
     else if (game == SPRL_GAME_GO7) emu::launch(block_entry_match<Go7>, &copy, P.num_slots);
     else if (game == SPRL_GAME_CONNECT_FOUR) emu::launch(block_entry_match<ConnectFour>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO9) emu::launch(block_entry_match_wide<GoN<9>>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO19) emu::launch(block_entry_match_wide<GoN<19>>, &copy, P.num_slots);
+    else if (game == SPRL_GAME_GO7W) emu::launch(block_entry_match_wide<GoN<7>>, &copy, P.num_slots);
     else return -1;
     return 0;
 }

@@ -81,7 +81,7 @@ def match_config(lib, game, **kw):
     return E.default_config(game, lib, **base)
 
 
-def check_match(lib, game, agents, num_games, seed=11, forwards=(None, None), oracle_forwards=(None, None), **cfg_kw):
+def check_match(lib, game, agents, num_games, seed=11, forwards=(None, None), oracle_forwards=(None, None), max_plies=160, **cfg_kw):
     """agents: two dicts(model=..., use_symmetry=..., parent_q=...).  Device match == oracle match, move for move."""
     cfg = match_config(lib, game, seed=seed, **cfg_kw)
     specs = []
@@ -90,7 +90,7 @@ def check_match(lib, game, agents, num_games, seed=11, forwards=(None, None), or
         if f is not None:
             s["forward"] = f
         specs.append(s)
-    winners, actions, nplies = E.play_match(cfg, specs[0], specs[1], num_games, max_plies=160, lib=lib)
+    winners, actions, nplies = E.play_match(cfg, specs[0], specs[1], num_games, max_plies=max_plies, lib=lib)
     ocfg = []
     for a, of in zip(agents, oracle_forwards):
         kind = po.EVAL_CALLBACK if of is not None else MATCH_EVAL[a["model"]]
@@ -99,7 +99,7 @@ def check_match(lib, game, agents, num_games, seed=11, forwards=(None, None), or
                                    use_sym=1 if a.get("use_symmetry", True) else 0, add_noise=cfg.add_noise,
                                    eval_kind=kind, math_mode=po.MATH_PORTABLE, mask_frame=cfg.mask_frame, forward=of,
                                    init_q=0 if a.get("parent_q", True) else 1))
-    ow, oa, on = po.match(ocfg[0], ocfg[1], num_games, seed, cfg.stream_base, max_plies=160)
+    ow, oa, on = po.match(ocfg[0], ocfg[1], num_games, seed, cfg.stream_base, max_plies=max_plies)
     assert (nplies == on).all(), (nplies, on)
     assert (actions == oa).all()
     assert (winners == ow).all()

@@ -230,6 +230,22 @@ def test_match_othello_random_vs_heuristic(emu):
 def test_match_go7_and_compaction(emu):
     agents = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="random", use_symmetry=True, parent_q=True)]
     parity.check_match(emu, "go", agents, 2, concurrent_games=2, num_traversals=24, max_batch=4, max_queue=2, node_cap=200)
+    # more games than pairs and a search that fits into ONE launch: the side that ends a game starts the pair's next game and may
+    # post its first move there before the partner has picked up the last move of the old game (found in round 3: the one-entry
+    # mailbox lost that move and the match stalled; the mailbox has two entries per slot now)
+    parity.check_match(emu, "go", agents, 3, concurrent_games=2, num_traversals=8, max_batch=4, max_queue=2)
+    parity.check_match(emu, "c4", agents, 7, concurrent_games=2, num_traversals=8, max_batch=4, max_queue=2)
+
+
+def test_match_wide_boards(emu):
+    """Evaluate.cpp-style matches on the multi-strip kernel (round 3: play.hpp:24-70 for boards wider than 8): Go 7x7 through the
+    wide kernel and Go 9x9, agents with different symmetrisation / InitQ, a forced compaction - move lists, lengths and winners
+    equal the oracle's playGame restatement."""
+    agents = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="random", use_symmetry=False, parent_q=False)]
+    parity.check_match(emu, "go7_wide", agents, 3, concurrent_games=2, num_traversals=24, max_batch=4, max_queue=2, max_plies=120)
+    parity.check_match(emu, "go9", agents, 2, concurrent_games=2, num_traversals=20, max_batch=4, max_queue=2, max_plies=200, seed=5)
+    parity.check_match(emu, "go9", agents[::-1], 2, concurrent_games=1, num_traversals=16, max_batch=4, max_queue=2, max_plies=200, seed=6,
+                       node_cap=160, spare_arenas=2)
 
 
 def test_match_network_agents_toy_forward(emu):

@@ -369,6 +369,17 @@ def test_match_c4_and_go7(lib):
     parity.check_match(lib, "go", a, 4, concurrent_games=4, num_traversals=64, node_cap=300, spare_arenas=4)
 
 
+def test_match_wide_boards(lib):
+    """Match play on boards wider than 8 (VERDICT r2 missing #5; interface/play.hpp:24-70 through step_kernel_wide.h: step_match):
+    Go 9x9 with agents of different symmetrisation / InitQ, more games than resident pairs, and one 19x19 game - move lists, lengths
+    and winners equal the oracle's restatement of playGame."""
+    agents = [dict(model="random", use_symmetry=True, parent_q=True), dict(model="random", use_symmetry=False, parent_q=False)]
+    w, a, n = parity.check_match(lib, "go9", agents, 6, concurrent_games=4, num_traversals=64, max_plies=200, seed=21)
+    assert (n > 20).all()
+    parity.check_match(lib, "go9", agents[::-1], 3, concurrent_games=2, num_traversals=8, max_batch=4, max_queue=2, max_plies=200, seed=22)
+    parity.check_match(lib, "go19", agents, 1, concurrent_games=1, num_traversals=32, max_plies=740, seed=23)
+
+
 def test_match_two_network_agents_toy_forward(lib):
     """Both agents evaluate through forward hooks on DEVICE buffers; the dense batch is split per agent."""
     import torch

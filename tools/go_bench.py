@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=400)
     ap.add_argument("--warm", type=int, default=20, help="rounds played before the timed ones (100 rounds = one move)")
     ap.add_argument("--no-cnn", action="store_true")
+    ap.add_argument("--cnn-only", action="store_true")
     ap.add_argument("--only", default=None, choices=["go9", "go19"])
     ap.add_argument("--lib", default=None, help="alternative libsprl_amd.so (A/B measurements)")
     ap.add_argument("--blocks", type=int, default=6)          # go_controller.py: MODEL_NUM_BLOCKS = 6
@@ -52,7 +53,7 @@ def main():
                 continue
             cnn = trace_to_file(make_network(game, a.blocks, 64, seed=0), os.path.join(td, f"{game}.pt"), game)
             for name, model, rounds in (("uniform evaluator (in kernel)", "random", a.rounds), ("traced CNN", cnn, a.rounds // 4)):
-                if a.no_cnn and model != "random":
+                if (a.no_cnn and model != "random") or (a.cnn_only and model == "random"):
                     continue
                 dt, d, info = measure(game, games, model, rounds, a.warm)
                 print(f"{game}: {games} games, {name} [{info}]: {rounds} rounds in {dt:.2f} s -> "
