@@ -135,13 +135,15 @@ GAMES = {
                          label="Connect Four 6x7", sym="mirror", noise="Dirichlet(0.25,0.5)", mask_bytes=8, board_bytes=42),
     "go7": dict(engine="go7", rows=7, cols=7, A=50, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8",
                 label="Go 7x7", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=8, board_bytes=49),
-    # resident games (round 3): 2048 for 9x9 / 1024 for 19x19 - the wide tree kernel now keeps 4-8 waves per CU resident (its
-    # position history left LDS), and larger network batches fill the any-board convolution better (profiles/r03l_bench_go*.json)
-    "go9": dict(engine="go9", rows=9, cols=9, A=82, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8",
+    # resident games (round 3): 4096 for 9x9 / 2048 for 19x19 (two populations of half that) - the wide tree kernel now keeps
+    # 4-8 waves per CU resident (its position history left LDS), a population's tree launch then fills every SIMD, and larger
+    # network batches fill the any-board convolution better (profiles/r03l_*, r03t_bench_go*.json: 9x9 14.6 games/s at 2048
+    # resident games, 15.7 at 4096; 19x19 5.9 at 1024, 6.1 at 2048).  A step is 4-6 minutes: --steps defaults to 1 for Go.
+    "go9": dict(engine="go9", rows=9, cols=9, A=82, planes=17, concurrent=4096, traversals=1600, blocks=6, bq="16/8", steps=1,
                 label="Go 9x9", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=11, board_bytes=81, populations=2),
     # config 5 names a resign threshold: on by default for this game (with random-init weights the decision is noise and games
     # end after ~min-ply moves; without it every game runs to the 722-ply cap, ~20 min per step)
-    "go19": dict(engine="go19", rows=19, cols=19, A=362, planes=17, concurrent=1024, traversals=1600, blocks=6, bq="16/8",
+    "go19": dict(engine="go19", rows=19, cols=19, A=362, planes=17, concurrent=2048, traversals=1600, blocks=6, bq="16/8", steps=1,
                  label="Go 19x19", sym="D4", noise="Dirichlet(0.25,0.2)", mask_bytes=46, board_bytes=361,
                  resign_threshold=0.05, resign_min_ply=60, populations=2),
 }
@@ -150,7 +152,7 @@ GAMES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 2; 1 for the Go configurations, whose steps take minutes)")
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--game", default="othello", choices=sorted(GAMES),
                     help="othello = the BASELINE metric (config 2/3); go9 / go19 = BASELINE configs 4 / 5")
@@ -180,6 +182,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
     G = GAMES[args.game]
+    args.steps = args.steps or G.get("steps", 2)
     args.concurrent = args.concurrent or G["concurrent"]
     args.traversals = args.traversals or G["traversals"]
     args.blocks = args.blocks or G["blocks"]

@@ -2,7 +2,7 @@
 device match engine (`sprl_match_play`): all games of the match run concurrently, two trees per game.
 
     python -m sprl_amd.evaluate <modelPath0> <modelPath1> <numGames> <numTraversals> <maxBatchSize> <maxQueueSize> \\
-        <model0UseSymmetrize> <model0UseParentQ> <model1UseSymmetrize> <model1UseParentQ> [--game othello|connect_four|go7]
+        <model0UseSymmetrize> <model0UseParentQ> <model1UseSymmetrize> <model1UseParentQ> [--game othello|connect_four|go7|go9|go19]
 
 "random" as a model path selects the uniform evaluator (Evaluate.cpp:72-74); "heuristic" the Othello heuristic.
 The reference binary is compiled for one game at a time (Evaluate.cpp:55-67); here it is the --game option.
@@ -27,7 +27,7 @@ def main(argv=None):
     ap.add_argument("parent_q0", type=int)
     ap.add_argument("sym1", type=int)
     ap.add_argument("parent_q1", type=int)
-    ap.add_argument("--game", default="connect_four", choices=["othello", "connect_four", "go7"])
+    ap.add_argument("--game", default="connect_four", choices=["othello", "connect_four", "go7", "go9", "go19"])
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--seed", type=int, default=None, help="default: from the clock, like the reference")
     ap.add_argument("--concurrent", type=int, default=4096)
