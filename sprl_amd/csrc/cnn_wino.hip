@@ -74,6 +74,39 @@ __device__ __forceinline__ void inverse_transform(const float (&m)[6][6], float 
     }
 }
 
+// The same for TWO output components at once.  Stage 1 (columns) runs on register pairs - acc[p][0:1] and acc[p][2:3] are aligned
+// pairs of the 16x16x4 accumulator tile, so v_pk_add_f32 / v_pk_fma_f32 do two components per instruction; stage 2 (rows) reads
+// the halves of those pairs (sub-registers are free) and writes each component's 4x4 output into its own registers, ready for the
+// 16-byte stores - no shuffles.  60 + 2 x 40 = 140 instructions for two components instead of 200.
+__device__ __forceinline__ void inverse_transform_pair(const f2 (&m)[6][6], float (&o0)[4][4], float (&o1)[4][4]) {
+    f2 tm[4][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const f2 s12 = m[1][b] + m[2][b], d12 = m[1][b] - m[2][b], s34 = m[3][b] + m[4][b], d34 = m[3][b] - m[4][b];
+        tm[0][b] = m[0][b] + s12 + s34;
+        tm[1][b] = d12 + 2.0f * d34;
+        tm[2][b] = s12 + 4.0f * s34;
+        tm[3][b] = d12 + 8.0f * d34 + m[5][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        {
+            const float s12 = tm[i][1][0] + tm[i][2][0], d12 = tm[i][1][0] - tm[i][2][0], s34 = tm[i][3][0] + tm[i][4][0], d34 = tm[i][3][0] - tm[i][4][0];
+            o0[i][0] = tm[i][0][0] + s12 + s34;
+            o0[i][1] = d12 + 2.0f * d34;
+            o0[i][2] = s12 + 4.0f * s34;
+            o0[i][3] = d12 + 8.0f * d34 + tm[i][5][0];
+        }
+        {
+            const float s12 = tm[i][1][1] + tm[i][2][1], d12 = tm[i][1][1] - tm[i][2][1], s34 = tm[i][3][1] + tm[i][4][1], d34 = tm[i][3][1] - tm[i][4][1];
+            o1[i][0] = tm[i][0][1] + s12 + s34;
+            o1[i][1] = d12 + 2.0f * d34;
+            o1[i][2] = s12 + 4.0f * s34;
+            o1[i][3] = d12 + 8.0f * d34 + tm[i][5][1];
+        }
+    }
+}
+
 // head convolutions fused behind the last trunk convolution (HEADS = 1: 2 policy + 1 value head channels)
 struct HeadArgs {
     const float *hw, *hb;   // [3][64] weights (policy rows first), [3] biases
@@ -162,30 +195,36 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     auto produce = [&](int c) {
         const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
         float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
-        float wr[3][6];
+        // stage 1 (over the patch rows) on PAIRS of columns - packed v_pk_* instructions, two columns each; stage 2 (over the
+        // columns) reads the halves of those pairs
+        f2 wr[3][3];
         if (LAB_OFF(2)) return;                       // lab: no input transform
         if (wa == 0) {                                // (the wave-uniform branch outside the loop: one scheduling region per role)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
-                const float p = __builtin_fmaf(-4.0f, e2, e4), q = __builtin_fmaf(-4.0f, e1, e3);
-                wr[0][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
-                wr[1][j] = p + q;
-                wr[2][j] = p - q;
+            for (int jp = 0; jp < 3; ++jp) {
+                const int j = 2 * jp;
+                const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[RS + j], pp[RS + j + 1] }, e2 = { pp[2 * RS + j], pp[2 * RS + j + 1] },
+                         e3 = { pp[3 * RS + j], pp[3 * RS + j + 1] }, e4 = { pp[4 * RS + j], pp[4 * RS + j + 1] };
+                const f2 p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                wr[0][jp] = (4.0f * e0 + e4) - 5.0f * e2;
+                wr[1][jp] = p + q;
+                wr[2][jp] = p - q;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float e0 = pp[j], e1 = pp[RS + j], e2 = pp[2 * RS + j], e3 = pp[3 * RS + j], e4 = pp[4 * RS + j];
-                const float p = e3 - e1, d = e2 - e0;
-                wr[0][j] = __builtin_fmaf(2.0f, d, p);
-                wr[1][j] = __builtin_fmaf(-2.0f, d, p);
-                wr[2][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
+            for (int jp = 0; jp < 3; ++jp) {
+                const int j = 2 * jp;
+                const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[RS + j], pp[RS + j + 1] }, e2 = { pp[2 * RS + j], pp[2 * RS + j + 1] },
+                         e3 = { pp[3 * RS + j], pp[3 * RS + j + 1] }, e4 = { pp[4 * RS + j], pp[4 * RS + j + 1] };
+                const f2 p = e3 - e1, d = e2 - e0;
+                wr[0][jp] = p + 2.0f * d;
+                wr[1][jp] = p - 2.0f * d;
+                wr[2][jp] = (4.0f * e0 + e4) - 5.0f * e2;
             }
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+            const float w0 = wr[r][0][0], w1 = wr[r][0][1], w2 = wr[r][1][0], w3 = wr[r][1][1], w4 = wr[r][2][0], w5 = wr[r][2][1];
             const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3), p2 = w4 - w2, d2 = w3 - w1;
             vd[(r * 6 + 0) * 64] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
             vd[(r * 6 + 1) * 64] = p + q;
@@ -287,14 +326,17 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
                 for (int j = 0; j < 4; ++j) hp[HEADS ? o : 0][i][j] = 0.0f;
     }
+    float opair[2][4][4];                              // the 4x4 outputs of the two components of a pair
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         __builtin_amdgcn_sched_barrier(0);
-        float m[6][6];
+        if ((r & 1) == 0) {                            // components r, r + 1 together: stage 1 of the inverse transform on register pairs
+            f2 m[6][6];
 #pragma unroll
-        for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = acc[p][r];
-        float o[4][4];
-        inverse_transform(m, o);
+            for (int p = 0; p < 36; ++p) m[p / 6][p % 6] = (f2){ acc[p][r], acc[p][r + 1] };
+            inverse_transform_pair(m, opair[0], opair[1]);
+        }
+        const float (&o)[4][4] = opair[r & 1];
         const int k = 16 * kb + 4 * c_sub + r;
         const float sc = scale[k], sh = shift[k];
         float hwk[OC];
@@ -599,29 +641,33 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         float* vd = v_buf + (c & 1) * 2 * VG + vdst0;
         if (LAB_OFF(2)) return;                        // lab: no input transform
         if (M == 4) {
-            float wr[3][6];
+            f2 wr[3][3];                               // stage 1 on pairs of columns (packed instructions), as in the 8x8 kernel
             if (wa == 0) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
-                    const float p = __builtin_fmaf(-4.0f, e2, e4), q = __builtin_fmaf(-4.0f, e1, e3);
-                    wr[0][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
-                    wr[1][j] = p + q;
-                    wr[2][j] = p - q;
+                for (int jp = 0; jp < 3; ++jp) {
+                    const int j = 2 * jp;
+                    const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[6 + j], pp[7 + j] }, e2 = { pp[12 + j], pp[13 + j] },
+                             e3 = { pp[18 + j], pp[19 + j] }, e4 = { pp[24 + j], pp[25 + j] };
+                    const f2 p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                    wr[0][jp] = (4.0f * e0 + e4) - 5.0f * e2;
+                    wr[1][jp] = p + q;
+                    wr[2][jp] = p - q;
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const float e0 = pp[j], e1 = pp[6 + j], e2 = pp[12 + j], e3 = pp[18 + j], e4 = pp[24 + j];
-                    const float p = e3 - e1, d = e2 - e0;
-                    wr[0][j] = __builtin_fmaf(2.0f, d, p);
-                    wr[1][j] = __builtin_fmaf(-2.0f, d, p);
-                    wr[2][j] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
+                for (int jp = 0; jp < 3; ++jp) {
+                    const int j = 2 * jp;
+                    const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[6 + j], pp[7 + j] }, e2 = { pp[12 + j], pp[13 + j] },
+                             e3 = { pp[18 + j], pp[19 + j] }, e4 = { pp[24 + j], pp[25 + j] };
+                    const f2 p = e3 - e1, d = e2 - e0;
+                    wr[0][jp] = p + 2.0f * d;
+                    wr[1][jp] = p - 2.0f * d;
+                    wr[2][jp] = (4.0f * e0 + e4) - 5.0f * e2;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float w0 = wr[r][0], w1 = wr[r][1], w2 = wr[r][2], w3 = wr[r][3], w4 = wr[r][4], w5 = wr[r][5];
+                const float w0 = wr[r][0][0], w1 = wr[r][0][1], w2 = wr[r][1][0], w3 = wr[r][1][1], w4 = wr[r][2][0], w5 = wr[r][2][1];
                 const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3), p2 = w4 - w2, d2 = w3 - w1;
                 vd[(r * 6 + 0) * 64] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
                 vd[(r * 6 + 1) * 64] = p + q;
