@@ -267,7 +267,10 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // {K step 2c, ..., K step 2c+1, V(c+1), barrier} per phase, only the loop boundary sits elsewhere.
     // (Two activation chunks in flight - a second register set, the phases unrolled in pairs, as the F(3x3) any-board kernel does -
     // were measured here in round 3 and dropped: at 144 accumulators the pair of phases spills 42 registers, 210.5 -> 248.1 us,
-    // profiles/r03m_wino_lab_two_chunks_in_flight.log.)
+    // profiles/r03m_wino_lab_two_chunks_in_flight.log.  THREE workgroups per CU - the 36 positions in two passes of 18, 168 registers,
+    // 47 KB of LDS, the partial inverse transform of pass 0 parked in y - also measured and dropped: 278.7 us against 210.8 us;
+    // the second read of the activations and the round trip of the partial sums move 2.6x the bytes and every pass pays its own
+    // prologue.  The kernel is in the history at commit e8a3335, the run in profiles/r03w_lab_3wg.log.)
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * V_G2;
         if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
@@ -399,216 +402,6 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         const int b = i / (OC * HW);
         if (n0 + b < batch) ha.maps_out[(size_t)n0 * (OC * HW) + i] = maps[i];
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 3, SPRL_WINO_3WG=1): three workgroups per CU.  The stamps of the kernel above say that a workgroup spends
-// a third of its life in stretches without MFMAs of its own (prologue, the first phases' waits, the output stage) and that only
-// ONE other workgroup is there to cover them; a third needs <= 168 registers and <= 53 KB of LDS.  Here the 36 transform
-// positions are done in TWO PASSES of 18 (V rows 0-2, then 3-5): 72 accumulator registers, 5 filter quads, V buffers of 18
-// positions (LDS 47 KB).  A pass builds only its three rows of the input transform (stage 1 of the transform is done twice per
-// item, by the two threads that share its output columns), reads the activations again, and ends with ITS part of the inverse
-// transform, Y = A^T[:, rows] M[rows, :] A: pass 0 writes the partial sums to y, pass 1 reads them back (same lanes, same
-// addresses), adds its own, applies scale / shift / residual / ReLU and writes y.
-// ---------------------------------------------------------------------------------------------------
-constexpr int V_H3 = 18 * 64;                         // V of one group in one pass: [rr][c][c_sub][16 tiles]
-constexpr int LDS_FLOATS3 = 2 * IN_BUF2 + 4 * V_H3;   // 47.2 KB
-
-template <int H, int W, int RES>
-__global__ void __launch_bounds__(NTHR2, 3) wino_conv64_3wg_kernel(const float* __restrict__ x, const float* __restrict__ u,
-                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                   const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                                   int relu, const unsigned* __restrict__ batch_dev) {
-    if (batch_dev) {
-        const int real = (int)*batch_dev;
-        batch = real < batch ? real : batch;
-    }
-    if ((int)blockIdx.x * NIMG2 >= batch) return;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS3];
-    float* const in_buf = lds;                        // [2][IN_BUF2]
-    float* const v_buf = lds + 2 * IN_BUF2;           // [2 phases][2 groups][V_H3]
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c_sub = lane >> 4, tl = lane & 15;
-    const int gl = wave & 1, chh = wave >> 1;         // producer role: group of the chunk, output columns 3 chh .. 3 chh + 2
-    const int kb = wave;                              // consumer role: output channels 16kb..16kb+15
-    const int n0 = (int)blockIdx.x * NIMG2;
-
-    for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;    // borders stay zero for the whole kernel
-
-    int ldst[2], xvoff[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int f = tid + NTHR2 * it;
-        const int b = f >> 7, rem = f & 127;
-        const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
-        ldst[it] = (g2 * 4 + cs) * CS2 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
-        xvoff[it] = ((n0 + b) * 4096 + rem * 4) * 4;
-    }
-    const int patch00 = (gl * 4 + c_sub) * CS2 + board_off(tl >> 2) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4;
-    const int vdst0 = gl * V_H3 + (3 * chh) * 64 + lane;
-    const unsigned act_bytes = (unsigned)batch * 16384u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 36u * 4096u * 4u, 0x00020000);
-    const int ulane = lane * 16;
-    const int tile = tl & 3, ty = tile >> 1, tx = tile & 1;
-    const int ovoff = ((n0 + (tl >> 2)) * 4096 + kb * 1024 + c_sub * 16 + tile * 4) * 4;
-    const float relu_floor = relu ? 0.0f : -__builtin_inff();
-
-    f4 acc[18];
-    f4 pre[2];
-    f4 a[5];
-    auto gload_to = [&](int chunk, f4 (&dst)[2]) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-            dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[it], chunk * 2048, 2));
-    };
-    auto lstore_from = [&](float* buf, const f4 (&src)[2]) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = src[it][j];
-    };
-
-    auto run_pass = [&](auto pass_tag) {
-        constexpr int PS = decltype(pass_tag)::value;
-        const int patch0 = patch00 + PS * RS;          // pass 1's rows 3..5 use patch rows 1..5
-        // V rows 3 PS .. 3 PS + 2 of this thread's (channel, tile), output columns 3 chh .. 3 chh + 2
-        auto produce = [&](int c) {
-            const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
-            float* vd = v_buf + (c & 1) * 2 * V_H3 + vdst0;
-            f2 wr[3][3];
-#pragma unroll
-            for (int jp = 0; jp < 3; ++jp) {
-                const int j = 2 * jp;
-                const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[RS + j], pp[RS + j + 1] }, e2 = { pp[2 * RS + j], pp[2 * RS + j + 1] },
-                         e3 = { pp[3 * RS + j], pp[3 * RS + j + 1] }, e4 = { pp[4 * RS + j], pp[4 * RS + j + 1] };
-                if (PS == 0) {
-                    const f2 p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
-                    wr[0][jp] = (4.0f * e0 + e4) - 5.0f * e2;
-                    wr[1][jp] = p + q;
-                    wr[2][jp] = p - q;
-                } else {
-                    const f2 p = e3 - e1, d = e2 - e0;
-                    wr[0][jp] = p + 2.0f * d;
-                    wr[1][jp] = p - 2.0f * d;
-                    wr[2][jp] = (4.0f * e0 + e4) - 5.0f * e2;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const float w0 = wr[r][0][0], w1 = wr[r][0][1], w2 = wr[r][1][0], w3 = wr[r][1][1], w4 = wr[r][2][0], w5 = wr[r][2][1];
-                if (chh == 0) {
-                    const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3);
-                    vd[(r * 6 + 0) * 64] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
-                    vd[(r * 6 + 1) * 64] = p + q;
-                    vd[(r * 6 + 2) * 64] = p - q;
-                } else {
-                    const float p2 = w4 - w2, d2 = w3 - w1;
-                    vd[(r * 6 + 0) * 64] = __builtin_fmaf(2.0f, d2, p2);
-                    vd[(r * 6 + 1) * 64] = __builtin_fmaf(-2.0f, d2, p2);
-                    vd[(r * 6 + 2) * 64] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
-                }
-            }
-        };
-        // filter quads of this pass: global positions 18 PS + pp, i.e. quads 4 PS .. 4 PS + 4 of U4[p / 4][s][kb][lane][p % 4]
-        auto aload = [&](int s, int k) {
-            a[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, ulane, ((4 * PS + k) * 16 + s) * 4096 + kb * 1024, 0));
-        };
-        auto kstep = [&](const float* vg, int s, int chunk, auto first) {
-            constexpr bool FIRST = decltype(first)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if (chunk >= 0) gload_to(chunk, pre);
-#pragma unroll
-            for (int pp = 0; pp < 18; ++pp) {
-                constexpr int SH = PS ? 2 : 0;                       // 18 + pp = 16 + (pp + 2)
-                const int k = (pp + SH) >> 2, e = (pp + SH) & 3;
-                if (FIRST) acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], vg[pp * 64 + lane], (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
-                else acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], vg[pp * 64 + lane], acc[pp], 0, 0, 0);
-                const bool last_of_quad = pp == 17 || ((pp + 1 + SH) >> 2) != k;
-                if (last_of_quad && s + 1 < 16) aload(s + 1, k);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto phase = [&](int c) {
-            const float* vs = v_buf + (c & 1) * 2 * V_H3;
-            if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);
-            kstep(vs + V_H3, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{});
-            if (c + 1 < 8) produce(c + 1);
-            __syncthreads();
-            if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_H3, 2 * c + 2, -1, std::false_type{});
-        };
-        {
-            f4 first[2];
-            gload_to(0, first);
-            gload_to(1, pre);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) aload(0, k);
-            __syncthreads();                           // zero fill done (pass 0) / every wave has left the previous pass's K loop
-            lstore_from(in_buf, first);
-            lstore_from(in_buf + IN_BUF2, pre);
-        }
-        gload_to(2, pre);
-        __syncthreads();
-        produce(0);
-        __syncthreads();
-        kstep(v_buf, 0, -1, std::true_type{});
-        for (int c = 0; c < 8; ++c) phase(c);
-
-        // this pass's part of Y = A^T M A: rows 3 PS .. 3 PS + 2 of M
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            __builtin_amdgcn_sched_barrier(0);
-            f4 part[4], rv[4];
-            if (PS == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    part[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ry, ovoff + (r * 1024 + i * 256), 0, 0));
-                    if (RES) rv[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, 2));
-                }
-            }
-            float tm[4][6];
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const float m0 = acc[b][r], m1 = acc[6 + b][r], m2 = acc[12 + b][r];
-                if (PS == 0) {                         // A^T columns 0, 1, 2: [1 0 0 0], [1 1 1 1], [1 -1 1 -1]
-                    const float s12 = m1 + m2, d12 = m1 - m2;
-                    tm[0][b] = m0 + s12; tm[1][b] = d12; tm[2][b] = s12; tm[3][b] = d12;
-                } else {                               // A^T columns 3, 4, 5: [1 2 4 8], [1 -2 4 -8], [0 0 0 1]
-                    const float s34 = m0 + m1, d34 = m0 - m1;
-                    tm[0][b] = s34; tm[1][b] = 2.0f * d34; tm[2][b] = 4.0f * s34; tm[3][b] = __builtin_fmaf(8.0f, d34, m2);
-                }
-            }
-            const int k = 16 * kb + 4 * c_sub + r;
-            const float sc = scale[k], sh = shift[k];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float s12 = tm[i][1] + tm[i][2], d12 = tm[i][1] - tm[i][2], s34 = tm[i][3] + tm[i][4], d34 = tm[i][3] - tm[i][4];
-                f4 o;
-                o[0] = tm[i][0] + s12 + s34;
-                o[1] = __builtin_fmaf(2.0f, d34, d12);
-                o[2] = __builtin_fmaf(4.0f, s34, s12);
-                o[3] = __builtin_fmaf(8.0f, d34, d12) + tm[i][5];
-                if (PS == 0) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), ry, ovoff + (r * 1024 + i * 256), 0, 0);
-                } else {
-                    f4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = __builtin_fmaf(o[j] + part[i][j], sc, sh);
-                        if (RES) v[j] += rv[i][j];
-                        v[j] = __builtin_fmaxf(v[j], relu_floor);
-                        if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * 1024 + i * 256), 0, 2);
-                }
-            }
-        }
-    };
-    run_pass(std::integral_constant<int, 0>{});
-    run_pass(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1096,12 +889,6 @@ int launch_conv64(const float* x, const float* u, const float* scale, const floa
         else                                                                                                                            \
             hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);     \
     } while (0)
-    static const bool three_wg = getenv("SPRL_WINO_3WG") && atoi(getenv("SPRL_WINO_3WG")) != 0;
-    if (three_wg && !HEADS && H == 8 && W == 8) {     // experiment: three workgroups per CU, the positions in two passes
-        if (res) hipLaunchKernelGGL((wino_conv64_3wg_kernel<8, 8, 1>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
-        else hipLaunchKernelGGL((wino_conv64_3wg_kernel<8, 8, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
     if (H == 8 && W == 8) SPRL_LAUNCH_CONV(8, 8);
     else if (H == 6 && W == 7) SPRL_LAUNCH_CONV(6, 7);
     else if (H == 7 && W == 7) SPRL_LAUNCH_CONV(7, 7);
