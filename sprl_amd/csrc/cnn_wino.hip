@@ -113,15 +113,11 @@ struct HeadArgs {
     float* maps_out;        // ReLU'd head maps [batch][3 * H * W]; the FC layers run in sprl_tail_fc (cnn_epilogue.hip)
 };
 
-#ifndef SPRL_WINO_8B_OFF
-#define SPRL_WINO_8B_OFF 0                            // lab builds of the eight-board kernel: 4 no input transform, 64 filters once,
-#endif                                                // 128 no output stage, 256 no B-operand reads in the K steps
 #ifndef SPRL_WINO_DEEP4
 #define SPRL_WINO_DEEP4 0                             // 1: the F(4x4) layout-T kernel also keeps two activation chunks in flight
 #endif
 #ifdef SPRL_WINO_LAB
 __constant__ int wino_lab_dbg;
-__device__ unsigned long long* wino_lab_stamps;       // [workgroup][16] shader-clock stamps of wave 0 (eight-board kernel)
 #define LAB_OFF(bit) (wino_lab_dbg & (1 << (bit)))
 #else
 #define LAB_OFF(bit) 0
@@ -274,7 +270,13 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // profiles/r03m_wino_lab_two_chunks_in_flight.log.  THREE workgroups per CU - the 36 positions in two passes of 18, 168 registers,
     // 47 KB of LDS, the partial inverse transform of pass 0 parked in y - also measured and dropped: 278.7 us against 210.8 us;
     // the second read of the activations and the round trip of the partial sums move 2.6x the bytes and every pass pays its own
-    // prologue.  The kernel is in the history at commit e8a3335, the run in profiles/r03w_lab_3wg.log.)
+    // prologue.  The kernel is in the history at commit e8a3335, the run in profiles/r03w_lab_3wg.log.
+    // EIGHT boards per workgroup - 8 waves, wave (kb, ph) owns 16 channels x 32 tiles x 18 of the 36 positions, so every filter
+    // register feeds two MFMAs and the filter stream is halved; the partial inverse transforms of the two position halves are
+    // exchanged through LDS - was built too (commit 1e0bdac): correct, and the filter stream stops mattering (filters loaded once
+    // would save 3 % instead of 25 %), but with 131 KB of LDS there is ONE workgroup per CU, its eight waves reach the transform,
+    // the barrier and the output stage together, and nothing covers those stretches: 228.8 us against 210.8 us in the lab, 389.7
+    // against 419.1 games/s in the bench (profiles/r03x_*, r03y_bench_8b.json).)
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * V_G2;
         if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
@@ -406,303 +408,6 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         const int b = i / (OC * HW);
         if (n0 + b < batch) ha.maps_out[(size_t)n0 * (OC * HW) + i] = maps[i];
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// EIGHT boards per workgroup (SPRL_WINO_8B=1; round 3 experiment).  The lab says the kernel above loses a quarter of its time to
-// re-reading the 590 KB of transformed filters per FOUR boards (2 GB of L2 -> L1 traffic per launch).  Here a workgroup is 8 waves
-// and 8 boards: wave (kb, ph) owns output channels 16 kb .. 16 kb + 15 for ALL 32 tiles but only HALF of the transform positions
-// (V rows 3 ph .. 3 ph + 2): 18 positions x 2 tile blocks = the same 144 accumulator registers and the same 36 MFMAs per K step,
-// but every filter register now feeds two MFMAs - 4.5 filter quads per K step instead of 9.  The inverse transform is linear in
-// the rows of M, so each wave applies A^T[:, its rows] M[its rows, :] A to both tile blocks, hands the partial sums of the OTHER
-// tile block to its partner wave (kb, 1 - ph) through LDS (the images and V are dead by then), and finishes its own tile block:
-// scale / shift / residual / ReLU and the 16-byte stores.  LDS: 2 x 28.7 KB images + 73.7 KB V = 131 KB, one workgroup per CU
-// (2 waves per SIMD, 256 registers each - as above).
-// ---------------------------------------------------------------------------------------------------
-constexpr int NIMG3 = 8, NTHR3 = 512;
-constexpr int CS3 = 897;                              // channel-slot stride for 8 boards (== 1 mod 32)
-constexpr int IN_BUF3 = 8 * CS3;
-constexpr int V_G3 = 36 * 2 * 64;                     // V of one group: [p][tile block][c_sub][16 tiles]
-constexpr int LDS_FLOATS3 = 2 * IN_BUF3 + 4 * V_G3;   // 131 136 B; the exchange of the output stage needs 131 072 B
-
-template <int H, int W, int RES>
-__global__ void __launch_bounds__(NTHR3, 2) wino_conv64_8b_kernel(const float* __restrict__ x, const float* __restrict__ u,
-                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                  const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                                  int relu, const unsigned* __restrict__ batch_dev) {
-    if (batch_dev) {
-        const int real = (int)*batch_dev;
-        batch = real < batch ? real : batch;
-    }
-    if ((int)blockIdx.x * NIMG3 >= batch) return;
-    // lab: stages are switched off at COMPILE time here (-DSPRL_WINO_8B_OFF=mask) - a run-time test inside the pinned K step
-    // splits its scheduling region and costs 20 % by itself
-#define LAB8(bit) ((SPRL_WINO_8B_OFF >> (bit)) & 1)
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS3];
-    float* const in_buf = lds;                        // [2][IN_BUF3]
-    float* const v_buf = lds + 2 * IN_BUF3;           // [2 phases][2 groups][V_G3]
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c_sub = lane >> 4, tl = lane & 15;
-    const int gl = wave & 1, ptb = (wave >> 1) & 1, wa = wave >> 2;   // producer role: group of the chunk, tile block, transform rows 3wa..3wa+2
-    const int kb = wave & 3, ph = wave >> 2;                          // consumer role: output channels 16kb..16kb+15, V rows 3ph..3ph+2
-    const int n0 = (int)blockIdx.x * NIMG3;
-
-    for (int i = tid; i < 2 * IN_BUF3; i += NTHR3) lds[i] = 0.0f;    // borders stay zero for the whole kernel
-
-    int ldst[2], xvoff[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int f = tid + NTHR3 * it;
-        const int b = f >> 7, rem = f & 127;
-        const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
-        ldst[it] = (g2 * 4 + cs) * CS3 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
-        xvoff[it] = ((n0 + b) * 4096 + rem * 4) * 4;
-    }
-    const int patch0 = (gl * 4 + c_sub) * CS3 + board_off(ptb * 4 + (tl >> 2)) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
-    const int vdst0 = gl * V_G3 + ((3 * wa) * 6 * 2 + ptb) * 64 + lane;
-    const unsigned act_bytes = (unsigned)batch * 16384u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 36u * 4096u * 4u, 0x00020000);
-    const int ulane = lane * 16;
-    const int tile = tl & 3, ty = tile >> 1, tx = tile & 1;
-    // this wave FINISHES tile block ph (boards 4 ph .. 4 ph + 3)
-    const int ovoff = ((n0 + ph * 4 + (tl >> 2)) * 4096 + kb * 1024 + c_sub * 16 + tile * 4) * 4;
-    const float relu_floor = relu ? 0.0f : -__builtin_inff();
-#ifdef SPRL_WINO_LAB
-    unsigned long long* const stamps = wino_lab_stamps ? wino_lab_stamps + (size_t)blockIdx.x * 16 : nullptr;
-#define SPRL_STAMP(slot) do { if (stamps && tid == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SPRL_STAMP(slot) do { } while (0)
-#endif
-    SPRL_STAMP(0);
-
-    // everything from here on is instantiated once per position half (ph is wave-uniform; both instances execute the same
-    // sequence of barriers): the accumulators and the filter ring are indexed by compile-time constants only
-    auto body = [&](auto ph_tag) __attribute__((always_inline)) {
-    constexpr int PH = decltype(ph_tag)::value;
-    f4 acc[18][2];
-    f4 pre[2];
-    f4 a[5];
-    auto gload_to = [&](int chunk, f4 (&dst)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-            dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[it], chunk * 2048, 2));
-    };
-    auto lstore_from = [&](float* buf, const f4 (&src)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) buf[ldst[it] + j] = src[it][j];
-    };
-    auto produce = [&](int c) __attribute__((always_inline)) {
-        const float* pp = in_buf + (c & 1) * IN_BUF3 + patch0;
-        float* vd = v_buf + (c & 1) * 2 * V_G3 + vdst0;
-        f2 wr[3][3];
-        if (LAB8(2)) return;                       // lab: no input transform
-        if (PH == 0) {
-#pragma unroll
-            for (int jp = 0; jp < 3; ++jp) {
-                const int j = 2 * jp;
-                const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[RS + j], pp[RS + j + 1] }, e2 = { pp[2 * RS + j], pp[2 * RS + j + 1] },
-                         e3 = { pp[3 * RS + j], pp[3 * RS + j + 1] }, e4 = { pp[4 * RS + j], pp[4 * RS + j + 1] };
-                const f2 p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
-                wr[0][jp] = (4.0f * e0 + e4) - 5.0f * e2;
-                wr[1][jp] = p + q;
-                wr[2][jp] = p - q;
-            }
-        } else {
-#pragma unroll
-            for (int jp = 0; jp < 3; ++jp) {
-                const int j = 2 * jp;
-                const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[RS + j], pp[RS + j + 1] }, e2 = { pp[2 * RS + j], pp[2 * RS + j + 1] },
-                         e3 = { pp[3 * RS + j], pp[3 * RS + j + 1] }, e4 = { pp[4 * RS + j], pp[4 * RS + j + 1] };
-                const f2 p = e3 - e1, d = e2 - e0;
-                wr[0][jp] = p + 2.0f * d;
-                wr[1][jp] = p - 2.0f * d;
-                wr[2][jp] = (4.0f * e0 + e4) - 5.0f * e2;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float w0 = wr[r][0][0], w1 = wr[r][0][1], w2 = wr[r][1][0], w3 = wr[r][1][1], w4 = wr[r][2][0], w5 = wr[r][2][1];
-            const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3), p2 = w4 - w2, d2 = w3 - w1;
-            vd[(r * 6 + 0) * 128] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
-            vd[(r * 6 + 1) * 128] = p + q;
-            vd[(r * 6 + 2) * 128] = p - q;
-            vd[(r * 6 + 3) * 128] = __builtin_fmaf(2.0f, d2, p2);
-            vd[(r * 6 + 4) * 128] = __builtin_fmaf(-2.0f, d2, p2);
-            vd[(r * 6 + 5) * 128] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
-        }
-    };
-    // filter quads of this wave: positions 18 ph + pp, i.e. quads 4 ph .. 4 ph + 4 of U4[p / 4][s][kb][lane][p % 4]
-    auto aload = [&](int s, int k) __attribute__((always_inline)) {
-        a[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, ulane, ((4 * PH + k) * 16 + s) * 4096 + kb * 1024, 0));
-    };
-    // one K step: 18 positions x 2 tile blocks = 36 MFMAs, every filter register used twice
-    auto kstep = [&](const float* vg, int s, int chunk, auto first) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first)::value;
-        constexpr int SH = PH ? 2 : 0;                 // position 18 + pp sits in quad 4 + (pp + 2) / 4
-        __builtin_amdgcn_sched_barrier(0);
-        if (chunk >= 0) gload_to(chunk, pre);
-        // ONE address register per K step + immediate offsets: V ends beyond the 64 KB a ds_read immediate reaches from the start
-        // of LDS, and with a constant-folded base the compiler keeps an address register per position alive (46 spills)
-        int vo = (int)(vg - lds) * 4 + lane * 4;
-        asm volatile("" : "+v"(vo));
-        const char* const vb = reinterpret_cast<const char*>(lds) + vo;
-        // B operands four positions ahead of their MFMAs (256 MFMA cycles cover the LDS latency); the order is pinned - left to
-        // itself the scheduler reads a batch, waits for it and only then issues the batch's MFMAs
-        float bv[18][2];
-        auto bread = [&](int pp) __attribute__((always_inline)) {
-            if (LAB8(8)) { bv[pp][0] = bv[pp][1] = (float)lane; return; }
-            bv[pp][0] = *reinterpret_cast<const float*>(vb + ((18 * PH + pp) * 2 + 0) * 256);
-            bv[pp][1] = *reinterpret_cast<const float*>(vb + ((18 * PH + pp) * 2 + 1) * 256);
-        };
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) bread(pp);
-#pragma unroll
-        for (int pp = 0; pp < 18; ++pp) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int k = (pp + SH) >> 2, e = (pp + SH) & 3;
-            if (pp + 4 < 18) bread(pp + 4);
-            if (FIRST) {
-                acc[pp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], bv[pp][0], (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
-                acc[pp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], bv[pp][1], (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
-            } else {
-                acc[pp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], bv[pp][0], acc[pp][0], 0, 0, 0);
-                acc[pp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], bv[pp][1], acc[pp][1], 0, 0, 0);
-            }
-            const bool last_of_quad = pp == 17 || ((pp + 1 + SH) >> 2) != k;
-            if (last_of_quad && s + 1 < 16 && !LAB8(6)) aload(s + 1, k);     // (lab bit 6: the filter quads are loaded once)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto phase = [&](int c) __attribute__((always_inline)) {
-        const float* vs = v_buf + (c & 1) * 2 * V_G3;
-        if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF3, pre);
-        // the two waves of a SIMD are (kb, 0) and (kb, 1), in step with each other: one builds V while the other runs its K step
-        if (PH == 0 && c + 1 < 8) produce(c + 1);
-        kstep(vs + V_G3, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{});
-        if (PH == 1 && c + 1 < 8) produce(c + 1);
-        __syncthreads();
-        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G3, 2 * c + 2, -1, std::false_type{});
-    };
-
-    {
-        f4 first[2];
-        gload_to(0, first);
-        gload_to(1, pre);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) aload(0, k);
-        __syncthreads();                               // zero fill done
-        lstore_from(in_buf, first);
-        lstore_from(in_buf + IN_BUF3, pre);
-    }
-    gload_to(2, pre);
-    __syncthreads();
-    produce(0);
-    __syncthreads();
-    SPRL_STAMP(1);
-    kstep(v_buf, 0, -1, std::true_type{});
-    for (int c = 0; c < 7; ++c) {
-        phase(c);
-        SPRL_STAMP(2 + c);
-    }
-    // half of the residual rows are requested before the LAST K step (the activation registers are dead, the filter ring is not
-    // reloaded any more; all 64 registers do not fit): all waves of the workgroup reach the output stage together, nothing else
-    // would cover that HBM round trip
-    f4 rres[4][4];
-    if (RES) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, 2));
-    }
-    phase(7);
-    SPRL_STAMP(9);              // ends with a barrier behind the last K step: LDS is free from here on
-
-    // ---- output: partial inverse transforms, exchange with the partner wave, epilogue ----
-    // partial Y of rows 3 PH .. 3 PH + 2 of M, tile block TB, component r: four 16-byte output rows
-    auto part = [&](auto tb_tag, int r, f4 (&o)[4]) __attribute__((always_inline)) {
-        constexpr int TB = decltype(tb_tag)::value;
-        float tm[4][6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const float m0 = acc[b][TB][r], m1 = acc[6 + b][TB][r], m2 = acc[12 + b][TB][r];
-            if (PH == 0) {                             // A^T columns 0, 1, 2: [1 0 0 0], [1 1 1 1], [1 -1 1 -1]
-                const float s12 = m1 + m2, d12 = m1 - m2;
-                tm[0][b] = m0 + s12; tm[1][b] = d12; tm[2][b] = s12; tm[3][b] = d12;
-            } else {                                   // A^T columns 3, 4, 5: [1 2 4 8], [1 -2 4 -8], [0 0 0 1]
-                const float s34 = m0 + m1, d34 = m0 - m1;
-                tm[0][b] = s34; tm[1][b] = 2.0f * d34; tm[2][b] = 4.0f * s34; tm[3][b] = __builtin_fmaf(8.0f, d34, m2);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float s12 = tm[i][1] + tm[i][2], d12 = tm[i][1] - tm[i][2], s34 = tm[i][3] + tm[i][4], d34 = tm[i][3] - tm[i][4];
-            o[i][0] = tm[i][0] + s12 + s34;
-            o[i][1] = __builtin_fmaf(2.0f, d34, d12);
-            o[i][2] = __builtin_fmaf(4.0f, s34, s12);
-            o[i][3] = __builtin_fmaf(8.0f, d34, d12) + tm[i][5];
-        }
-    };
-    f4* const xb = reinterpret_cast<f4*>(lds);         // [wave][r * 4 + i][lane]
-#if SPRL_WINO_8B_OFF
-    if (LAB8(7)) {                                 // lab: no output stage (one store keeps the accumulators alive)
-        f4 sum = acc[0][0] + acc[0][1];
-#pragma unroll
-        for (int q = 1; q < 18; ++q) sum += acc[q][0] + acc[q][1];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, sum), ry, ovoff, 0, 2);
-        return;
-    }
-#endif
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                      // the OTHER tile block: to the partner
-        f4 o[4];
-        part(std::integral_constant<int, 1 - PH>{}, r, o);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xb[(wave * 16 + r * 4 + i) * 64 + lane] = o[i];
-    }
-    if (RES) {                                         // (half of the accumulators is dead: room for the other residual rows)
-#pragma unroll
-        for (int r = 2; r < 4; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, 2));
-    }
-    f4 own[4][4];                                      // this wave's tile block
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part(std::integral_constant<int, PH>{}, r, own[r]);
-    __syncthreads();
-    SPRL_STAMP(10);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int k = 16 * kb + 4 * c_sub + r;
-        const float sc = scale[k], sh = shift[k];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f4 other = xb[((wave ^ 4) * 16 + r * 4 + i) * 64 + lane];
-            f4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = __builtin_fmaf(own[r][i][j] + other[j], sc, sh);
-                if (RES) v[j] += rres[r][i][j];
-                v[j] = __builtin_fmaxf(v[j], relu_floor);
-                if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * 1024 + i * 256), 0, 2);
-        }
-    }
-    SPRL_STAMP(11);
-    };
-    if (ph == 0) body(std::integral_constant<int, 0>{});
-    else body(std::integral_constant<int, 1>{});
-#undef SPRL_STAMP
-#undef LAB8
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1190,13 +895,6 @@ int launch_conv64(const float* x, const float* u, const float* scale, const floa
         else                                                                                                                            \
             hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);     \
     } while (0)
-    static const bool eight = getenv("SPRL_WINO_8B") && atoi(getenv("SPRL_WINO_8B")) != 0;
-    if (eight && !HEADS && H == 8 && W == 8) {        // experiment: eight boards per workgroup, filters used twice
-        const dim3 grid8((unsigned)((batch + NIMG3 - 1) / NIMG3)), block8(NTHR3);
-        if (res) hipLaunchKernelGGL((wino_conv64_8b_kernel<8, 8, 1>), grid8, block8, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
-        else hipLaunchKernelGGL((wino_conv64_8b_kernel<8, 8, 0>), grid8, block8, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
     if (H == 8 && W == 8) SPRL_LAUNCH_CONV(8, 8);
     else if (H == 6 && W == 7) SPRL_LAUNCH_CONV(6, 7);
     else if (H == 7 && W == 7) SPRL_LAUNCH_CONV(7, 7);
@@ -1301,5 +999,4 @@ extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float
 
 #ifdef SPRL_WINO_LAB
 extern "C" int sprl_wino_lab_set_dbg(int mask) { return hipMemcpyToSymbol(HIP_SYMBOL(wino_lab_dbg), &mask, sizeof(int)) == hipSuccess ? 0 : -1; }
-extern "C" int sprl_wino_lab_set_stamps(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(wino_lab_stamps), &p, sizeof(void*)) == hipSuccess ? 0 : -1; }
 #endif

@@ -50,13 +50,7 @@ def main():
     flop = 2.0 * B * 4 * 36 * 64 * 64
     base = None
     print(f"8x8 trunk convolution, {B} boards, {os.path.basename(a.lib or nchw_lab.LIB)}")
-    eight = os.environ.get("SPRL_WINO_8B", "0") != "0"
-    has_lab = hasattr(L, "sprl_wino_lab_set_dbg")
-    if eight or not has_lab:                           # compile-time variants of the eight-board kernel: just time the library given
-        for name, with_res in (("with residual", True), ("no residual (RES = 0 variant)", False)):
-            us = timeit(with_res)
-            print(f"  {name:92s} {us:8.1f} us   {flop / us / 1e6 / 157.3:.3f}")
-    for name, mask, with_res in () if (eight or not has_lab) else (("everything on", 0, True), ("no residual (RES = 0 variant)", 0, False),
+    for name, mask, with_res in (("everything on", 0, True), ("no residual (RES = 0 variant)", 0, False),
                                  ("no input transform", 4, True), ("filter quads loaded once", 64, True),
                                  ("no output stage", 128, True),
                                  ("no transform + filters once + no output stage (MFMA loop + activation loads)", 4 + 64 + 128, True)):
@@ -64,25 +58,7 @@ def main():
         us = timeit(with_res)
         base = base or us
         print(f"  {name:92s} {us:8.1f} us  ({us - base:+7.1f})   {flop / us / 1e6 / 157.3:.3f}")
-    if has_lab:
-        L.sprl_wino_lab_set_dbg(0)
-    if eight and hasattr(L, "sprl_wino_lab_set_stamps"):      # eight boards per workgroup: where a workgroup's time goes (wave 0)
-        groups = (B + 7) // 8
-        st = torch.zeros(groups, 16, dtype=torch.int64, device="cuda")
-        L.sprl_wino_lab_set_stamps.argtypes = [C.c_void_p]
-        L.sprl_wino_lab_set_stamps(st.data_ptr())
-        for _ in range(3):
-            run(True)
-        torch.cuda.synchronize()
-        L.sprl_wino_lab_set_stamps(None)
-        h = st.cpu().double()
-        names = ["prologue"] + [f"phase{c}" for c in range(8)] + ["partials+exchange", "finish"]
-        print("  stamps (shader cycles per workgroup, wave 0): median / p10 / p90")
-        for k, nm in enumerate(names):
-            d = (h[:, k + 1] - h[:, k]).sort().values
-            print(f"    {nm:18s} {d[len(d) // 2]:9.0f} {d[len(d) // 10]:9.0f} {d[len(d) * 9 // 10]:9.0f}")
-        d = (h[:, 11] - h[:, 0]).sort().values
-        print(f"    {'total':18s} {d[len(d) // 2]:9.0f} {d[len(d) // 10]:9.0f} {d[len(d) * 9 // 10]:9.0f}")
+    L.sprl_wino_lab_set_dbg(0)
 
 
 if __name__ == "__main__":
