@@ -161,9 +161,6 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
         ldst[it] = (g2 * 4 + cs) * CS2 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
         xvoff[it] = ((n0 + b) * 4096 + rem * 4) * 4;  // the per-lane offset carries the board: the range check drops boards >= batch
-#ifdef SPRL_WINO_LAB_XL2                              // lab build: every workgroup reads the FIRST four boards (activations from L2; wrong results)
-        xvoff[it] = (b * 4096 + rem * 4) * 4;
-#endif
     }
     const int patch0 = (gl * 4 + c_sub) * CS2 + board_off(tl >> 2) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
     const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
@@ -279,7 +276,11 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // exchanged through LDS - was built too (commit 1e0bdac): correct, and the filter stream stops mattering (filters loaded once
     // would save 3 % instead of 25 %), but with 131 KB of LDS there is ONE workgroup per CU, its eight waves reach the transform,
     // the barrier and the output stage together, and nothing covers those stretches: 228.8 us against 210.8 us in the lab, 389.7
-    // against 419.1 games/s in the bench (profiles/r03x_*, r03y_bench_8b.json).)
+    // against 419.1 games/s in the bench (profiles/r03x_*, r03y_bench_8b.json).  EIGHT WAVES of 128 registers on the same four
+    // boards (wave (kb, ph) with 72 accumulators, four waves per SIMD, two workgroups of eight per CU; commit e7706f2, see
+    // DESIGN.md section 5): 227.8 us against 212.7 us - more streams do not help either.  What the PMC says instead: the filter
+    // stream is 11.7 TB/s of L2-to-CU traffic, two thirds of the practical L2 rate, at an L2 latency of 271 cycles - a bandwidth,
+    // not a latency (tools/conv_pmc.sh, profiles/r03z_conv_pmc_*).)
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * V_G2;
         if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
@@ -411,238 +412,6 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         const int b = i / (OC * HW);
         if (n0 + b < batch) ha.maps_out[(size_t)n0 * (OC * HW) + i] = maps[i];
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// EIGHT waves per workgroup at 128 registers (SPRL_WINO_W8=1; round 3 experiment).  Same four boards, same LDS images and V as the
-// kernel above, but wave (kb, ph) owns only HALF of the transform positions (V rows 3 ph .. 3 ph + 2) of its 16 output channels:
-// 72 accumulator registers instead of 144, so FOUR waves fit a SIMD and a CU holds two workgroups of eight - twice the number of
-// instruction streams to cover the prologue, the first phases' waits and the output stage of the other workgroup.  The filter
-// stream, the LDS reads and the MFMA count per workgroup are unchanged.  The inverse transform is linear in the rows of M: each
-// wave applies A^T[:, its rows] M[its rows, :] A, hands the partial sums of two of its four channel components to its partner
-// wave (kb, 1 - ph) through LDS (the images and V are dead by then) and finishes the other two.
-// ---------------------------------------------------------------------------------------------------
-constexpr int NTHR4 = 512;
-
-template <int H, int W, int RES>
-__global__ void __launch_bounds__(NTHR4, 4) wino_conv64_w8_kernel(const float* __restrict__ x, const float* __restrict__ u,
-                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                  const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                                  int relu, const unsigned* __restrict__ batch_dev) {
-    if (batch_dev) {
-        const int real = (int)*batch_dev;
-        batch = real < batch ? real : batch;
-    }
-    if ((int)blockIdx.x * NIMG2 >= batch) return;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS2];
-    float* const in_buf = lds;                        // [2][IN_BUF2]
-    float* const v_buf = lds + 2 * IN_BUF2;           // [2 phases][2 groups][V_G2]
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c_sub = lane >> 4, tl = lane & 15;
-    const int gl = wave & 1, colh = (wave >> 1) & 1;  // producer role: group of the chunk, V columns 3 colh .. 3 colh + 2 (rows: 3 ph ..)
-    const int kb = wave & 3, ph = wave >> 2;          // consumer role: output channels 16kb..16kb+15, V rows 3ph..3ph+2
-    const int n0 = (int)blockIdx.x * NIMG2;
-
-    for (int i = tid; i < 2 * IN_BUF2; i += NTHR4) lds[i] = 0.0f;    // borders stay zero for the whole kernel
-
-    int ldst, xvoff;                                  // one 16-byte piece of a chunk per thread
-    {
-        const int b = tid >> 7, rem = tid & 127;
-        const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
-        ldst = (g2 * 4 + cs) * CS2 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
-        xvoff = ((n0 + b) * 4096 + rem * 4) * 4;
-    }
-    const int patch0 = (gl * 4 + c_sub) * CS2 + board_off(tl >> 2) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + ph * RS + colh;
-    const int vdst0 = gl * V_G2 + (3 * ph * 6 + 3 * colh) * 64 + lane;
-    const unsigned act_bytes = (unsigned)batch * 16384u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, res ? act_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, 36u * 4096u * 4u, 0x00020000);
-    const int ulane = lane * 16;
-    const int tile = tl & 3, ty = tile >> 1, tx = tile & 1;
-    // this wave FINISHES channel components 2 ph and 2 ph + 1 of its 16 channels
-    const int ovoff = ((n0 + (tl >> 2)) * 4096 + kb * 1024 + c_sub * 16 + tile * 4) * 4 + ph * 2048;
-    const float relu_floor = relu ? 0.0f : -__builtin_inff();
-
-    // everything from here on is instantiated once per position half (ph is wave-uniform; both instances execute the same
-    // sequence of barriers): the accumulators and the filter ring are indexed by compile-time constants only
-    auto body = [&](auto ph_tag) __attribute__((always_inline)) {
-    constexpr int PH = decltype(ph_tag)::value;
-    f4 acc[18];
-    f4 pre;
-    f4 a[5];
-    auto gload = [&](int chunk) __attribute__((always_inline)) {
-        pre = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff, chunk * 2048, 2));
-    };
-    auto lstore = [&](float* buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) buf[ldst + j] = pre[j];
-    };
-    // V rows 3 PH .. 3 PH + 2, columns 3 colh .. 3 colh + 2 of this thread's (channel, tile).  128 registers hold 72 accumulators
-    // and the 20 of the filter ring, so the transform is written to need few: columns first, one patch row at a time (five loads,
-    // three results; the order is pinned - the scheduler would fetch the whole patch first), then the three rows per column.
-    auto produce = [&](int c) __attribute__((always_inline)) {
-        const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;       // (patch0 carries the row offset PH and the column offset colh)
-        float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
-        float t[5][3];
-        if (colh == 0) {
-#pragma unroll
-            for (int row = 0; row < 5; ++row) {
-                __builtin_amdgcn_sched_barrier(0);
-                const float w0 = pp[row * RS], w1 = pp[row * RS + 1], w2 = pp[row * RS + 2], w3 = pp[row * RS + 3], w4 = pp[row * RS + 4];
-                const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3);
-                t[row][0] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
-                t[row][1] = p + q;
-                t[row][2] = p - q;
-            }
-        } else {
-#pragma unroll
-            for (int row = 0; row < 5; ++row) {                      // columns 3, 4, 5 from patch columns 1 .. 5 (pp starts at column 1)
-                __builtin_amdgcn_sched_barrier(0);
-                const float w1 = pp[row * RS], w2 = pp[row * RS + 1], w3 = pp[row * RS + 2], w4 = pp[row * RS + 3], w5 = pp[row * RS + 4];
-                const float p2 = w4 - w2, d2 = w3 - w1;
-                t[row][0] = __builtin_fmaf(2.0f, d2, p2);
-                t[row][1] = __builtin_fmaf(-2.0f, d2, p2);
-                t[row][2] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int col = 0; col < 3; ++col) {
-            const float e0 = t[0][col], e1 = t[1][col], e2 = t[2][col], e3 = t[3][col], e4 = t[4][col];
-            if (PH == 0) {
-                const float p = __builtin_fmaf(-4.0f, e2, e4), q = __builtin_fmaf(-4.0f, e1, e3);
-                vd[(0 * 6 + col) * 64] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
-                vd[(1 * 6 + col) * 64] = p + q;
-                vd[(2 * 6 + col) * 64] = p - q;
-            } else {
-                const float p = e3 - e1, d = e2 - e0;
-                vd[(0 * 6 + col) * 64] = __builtin_fmaf(2.0f, d, p);
-                vd[(1 * 6 + col) * 64] = __builtin_fmaf(-2.0f, d, p);
-                vd[(2 * 6 + col) * 64] = __builtin_fmaf(-5.0f, e2, __builtin_fmaf(4.0f, e0, e4));
-            }
-        }
-    };
-    // filter quads of this wave: positions 18 PH + pp, i.e. quads 4 PH .. 4 PH + 4 of U4[p / 4][s][kb][lane][p % 4]
-    auto aload = [&](int s, int k) __attribute__((always_inline)) {
-        a[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ru, ulane, ((4 * PH + k) * 16 + s) * 4096 + kb * 1024, 0));
-    };
-    auto kstep = [&](const float* vg, int s, int chunk, auto first) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first)::value;
-        constexpr int SH = PH ? 2 : 0;                 // position 18 + pp sits in quad 4 + (pp + 2) / 4
-        __builtin_amdgcn_sched_barrier(0);
-        if (chunk >= 0) gload(chunk);
-        // B operands four positions ahead of their MFMAs, in a pinned order (few registers in flight)
-        float bv[18];
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) bv[pp] = vg[(18 * PH + pp) * 64 + lane];
-#pragma unroll
-        for (int pp = 0; pp < 18; ++pp) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int k = (pp + SH) >> 2, e = (pp + SH) & 3;
-            if (pp + 4 < 18) bv[pp + 4] = vg[(18 * PH + pp + 4) * 64 + lane];
-            if (FIRST) acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], bv[pp], (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);
-            else acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], bv[pp], acc[pp], 0, 0, 0);
-            const bool last_of_quad = pp == 17 || ((pp + 1 + SH) >> 2) != k;
-            if (last_of_quad) aload(s + 1 < 16 ? s + 1 : 15, k);      // (no branch inside the K step: the last one reloads its own quads)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto phase = [&](int c) __attribute__((always_inline)) {
-        const float* vs = v_buf + (c & 1) * 2 * V_G2;
-        if (c + 2 < 8) lstore(in_buf + (c & 1) * IN_BUF2);
-        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{});
-        if (c + 1 < 8) produce(c + 1);
-        __syncthreads();
-        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G2, 2 * c + 2, -1, std::false_type{});
-    };
-
-    {
-        gload(0);
-        const f4 first = pre;
-        gload(1);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) aload(0, k);
-        __syncthreads();                               // zero fill done
-#pragma unroll
-        for (int j = 0; j < 4; ++j) in_buf[ldst + j] = first[j];
-        lstore(in_buf + IN_BUF2);
-    }
-    gload(2);
-    __syncthreads();
-    produce(0);
-    __syncthreads();
-    kstep(v_buf, 0, -1, std::true_type{});
-#pragma nounroll
-    for (int c = 0; c < 8; ++c) phase(c);              // ends with a barrier behind the last K step: LDS is free from here on
-
-    // ---- output: partial inverse transform, exchange with the partner wave, epilogue ----
-    auto part = [&](int r, f4 (&o)[4]) __attribute__((always_inline)) {
-        float tm[4][6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const float m0 = acc[b][r], m1 = acc[6 + b][r], m2 = acc[12 + b][r];
-            if (PH == 0) {                             // A^T columns 0, 1, 2: [1 0 0 0], [1 1 1 1], [1 -1 1 -1]
-                const float s12 = m1 + m2, d12 = m1 - m2;
-                tm[0][b] = m0 + s12; tm[1][b] = d12; tm[2][b] = s12; tm[3][b] = d12;
-            } else {                                   // A^T columns 3, 4, 5: [1 2 4 8], [1 -2 4 -8], [0 0 0 1]
-                const float s34 = m0 + m1, d34 = m0 - m1;
-                tm[0][b] = s34; tm[1][b] = 2.0f * d34; tm[2][b] = 4.0f * s34; tm[3][b] = __builtin_fmaf(8.0f, d34, m2);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float s12 = tm[i][1] + tm[i][2], d12 = tm[i][1] - tm[i][2], s34 = tm[i][3] + tm[i][4], d34 = tm[i][3] - tm[i][4];
-            o[i][0] = tm[i][0] + s12 + s34;
-            o[i][1] = __builtin_fmaf(2.0f, d34, d12);
-            o[i][2] = __builtin_fmaf(4.0f, s34, s12);
-            o[i][3] = __builtin_fmaf(8.0f, d34, d12) + tm[i][5];
-        }
-    };
-    f4* const xb = reinterpret_cast<f4*>(lds);         // [wave][rr * 4 + i][lane]: 64 KB
-#pragma unroll
-    for (int rr2 = 0; rr2 < 2; ++rr2) {                // components 2 (1 - PH) + rr2: to the partner
-        f4 o[4];
-        part(2 * (1 - PH) + rr2, o);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xb[(wave * 8 + rr2 * 4 + i) * 64 + lane] = o[i];
-    }
-    f4 rres[2][4];
-    if (RES) {
-#pragma unroll
-        for (int rr2 = 0; rr2 < 2; ++rr2)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rres[rr2][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (rr2 * 1024 + i * 256), 0, 2));
-    }
-    f4 own[2][4];
-#pragma unroll
-    for (int rr2 = 0; rr2 < 2; ++rr2) part(2 * PH + rr2, own[rr2]);
-    __syncthreads();
-#pragma unroll
-    for (int rr2 = 0; rr2 < 2; ++rr2) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int k = 16 * kb + 4 * c_sub + 2 * PH + rr2;
-        const float sc = scale[k], sh = shift[k];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f4 other = xb[((wave ^ 4) * 8 + rr2 * 4 + i) * 64 + lane];
-            f4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = __builtin_fmaf(own[rr2][i][j] + other[j], sc, sh);
-                if (RES) v[j] += rres[rr2][i][j];
-                v[j] = __builtin_fmaxf(v[j], relu_floor);
-                if (4 * ty + i >= H || 4 * tx + j >= W) v[j] = 0.0f;
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (rr2 * 1024 + i * 256), 0, 2);
-        }
-    }
-    };
-    if (ph == 0) body(std::integral_constant<int, 0>{});
-    else body(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1130,12 +899,6 @@ int launch_conv64(const float* x, const float* u, const float* scale, const floa
         else                                                                                                                            \
             hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);     \
     } while (0)
-    static const bool w8 = getenv("SPRL_WINO_W8") && atoi(getenv("SPRL_WINO_W8")) != 0;
-    if (w8 && !HEADS && H == 8 && W == 8) {           // experiment: eight waves of 128 registers per workgroup
-        if (res) hipLaunchKernelGGL((wino_conv64_w8_kernel<8, 8, 1>), grid, dim3(NTHR4), 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
-        else hipLaunchKernelGGL((wino_conv64_w8_kernel<8, 8, 0>), grid, dim3(NTHR4), 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
     if (H == 8 && W == 8) SPRL_LAUNCH_CONV(8, 8);
     else if (H == 6 && W == 7) SPRL_LAUNCH_CONV(6, 7);
     else if (H == 7 && W == 7) SPRL_LAUNCH_CONV(7, 7);
