@@ -297,6 +297,117 @@ __global__ void __launch_bounds__(256) tail_kernel(const float* __restrict__ x, 
         if (t16 == 0) value[n] = tanhf(part + vfc2_b[0]);
     }
 }
+
+// The FC layers of the tail on the fp32 matrix cores, for head maps that the last trunk convolution already produced
+// (maps_in of tail_kernel above; sprl_wino_conv64_heads).  tail_kernel's stage 2 walks the FC weights in LDS once per board and
+// output - two LDS reads per multiply-add, 40 us per round of 13.5 k Othello boards, LDS-bound.  Here a workgroup takes 64 boards,
+// a wave 16 of them: logits[16 boards][A] = maps[16][PIN] x W[PIN][A] as v_mfma_f32_16x16x4_f32 tiles with the boards as rows
+// (A operand: one map value per lane, B operand: one weight per lane, both conflict-free LDS reads: the map rows are 194 floats
+// apart, the weight rows 80), the hidden layer of the value head the same way, then bias / ReLU / the 64-long dot product with
+// vfc2 (a 16-lane reduction) / tanh in registers.  Weights past A / HID and map columns past the board are zero in LDS, so the
+// contraction is padded to a multiple of 4 without a branch.
+constexpr int TFC_NB = 64, TFC_LDW = 80, TFC_LDM = 194, TFC_MAXNBLK = TAIL_MAXA / 16;
+
+__global__ void __launch_bounds__(256) tail_fc_mfma_kernel(const float* __restrict__ maps_in, const float* __restrict__ pfc_w,
+                                                           const float* __restrict__ pfc_b, const float* __restrict__ vfc1_w,
+                                                           const float* __restrict__ vfc1_b, const float* __restrict__ vfc2_w,
+                                                           const float* __restrict__ vfc2_b, float* __restrict__ logits,
+                                                           float* __restrict__ value, int batch, int PIN, int VIN, int A, int HID,
+                                                           const unsigned* __restrict__ batch_dev) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if (batch_dev) {
+        const int real = (int)*batch_dev;
+        batch = real < batch ? real : batch;
+    }
+    const int n0 = (int)blockIdx.x * TFC_NB;
+    if (n0 >= batch) return;
+    const int KP = (PIN + 3) >> 2, KV = (VIN + 3) >> 2, OCHW = PIN + VIN;
+    extern __shared__ float fsh[];
+    float* const s_pw = fsh;                           // [4 KP][80]
+    float* const s_vw = s_pw + 4 * KP * TFC_LDW;       // [4 KV][80]
+    float* const s_maps = s_vw + 4 * KV * TFC_LDW;     // [64][194]
+    float* const s_pb = s_maps + TFC_NB * TFC_LDM;     // [80] policy bias, [64] hidden bias, [64] vfc2
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // LDS fill, eight independent loads in flight per thread (a rolled one-load loop is a chain of ~100 L2 round trips)
+    auto fill = [&](float* dst, int count, auto&& src) {
+        for (int i0 = tid; i0 < count; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i0 + 256 * u < count ? src(i0 + 256 * u) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 256 * u < count) dst[i0 + 256 * u] = v[u];
+        }
+    };
+    fill(s_pw, 4 * KP * TFC_LDW, [&](int i) {
+        const int q = i / TFC_LDW, a = i - q * TFC_LDW;
+        return (q < PIN && a < A) ? pfc_w[q * A + a] : 0.0f;
+    });
+    fill(s_vw, 4 * KV * TFC_LDW, [&](int i) {
+        const int q = i / TFC_LDW, j = i - q * TFC_LDW;
+        return (q < VIN && j < HID) ? vfc1_w[q * HID + j] : 0.0f;
+    });
+    fill(s_maps, TFC_NB * TFC_LDM, [&](int i) {
+        const int b = i / TFC_LDM, c = i - b * TFC_LDM;
+        return (c < OCHW && n0 + b < batch) ? maps_in[(size_t)(n0 + b) * OCHW + c] : 0.0f;
+    });
+    if (tid < TFC_LDW) s_pb[tid] = tid < A ? pfc_b[tid] : 0.0f;
+    if (tid < 64) {
+        s_pb[TFC_LDW + tid] = tid < HID ? vfc1_b[tid] : 0.0f;
+        s_pb[TFC_LDW + 64 + tid] = tid < HID ? vfc2_w[tid] : 0.0f;
+    }
+    __syncthreads();
+
+    const int row = lane & 15, kq = lane >> 4;         // A operand: board `row` of this wave, contraction index 4 s + kq
+    const float* am = s_maps + (wave * 16 + row) * TFC_LDM + kq;
+    const float* bw = s_pw + kq * TFC_LDW + row;        // B operand: weight row 4 s + kq, output column 16 nb + (lane & 15)
+    const int nblk = (A + 15) >> 4;
+    f4v accp[TFC_MAXNBLK], accv[4];
+#pragma unroll
+    for (int nb = 0; nb < TFC_MAXNBLK; ++nb) accp[nb] = (f4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) accv[nb] = (f4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int s = 0; s < KP; ++s) {
+        const float av = am[4 * s];
+#pragma unroll
+        for (int nb = 0; nb < TFC_MAXNBLK; ++nb)
+            if (nb < nblk) accp[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[4 * s * TFC_LDW + 16 * nb], accp[nb], 0, 0, 0);
+    }
+    const float* bv = s_vw + kq * TFC_LDW + row;
+    for (int s = 0; s < KV; ++s) {
+        const float av = am[PIN + 4 * s];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) accv[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[4 * s * TFC_LDW + 16 * nb], accv[nb], 0, 0, 0);
+    }
+    // D: lane holds boards 4 kq + r (r = 0..3) of this wave, column (lane & 15) of each 16-wide block
+    const int nrow0 = n0 + wave * 16 + 4 * kq;
+#pragma unroll
+    for (int nb = 0; nb < TFC_MAXNBLK; ++nb) {
+        const int a = 16 * nb + row;
+        if (nb < nblk && a < A) {
+            const float bias = s_pb[a];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (nrow0 + r < batch) logits[(size_t)(nrow0 + r) * A + a] = accp[nb][r] + bias;
+        }
+    }
+    float part[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const float hb1 = s_pb[TFC_LDW + 16 * nb + row], w2 = s_pb[TFC_LDW + 64 + 16 * nb + row];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h = accv[nb][r] + hb1;
+            part[r] += (h > 0.0f ? h : 0.0f) * w2;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) part[r] += __shfl_xor(part[r], m, 16);
+        if (row == 0 && nrow0 + r < batch) value[nrow0 + r] = tanhf(part[r] + vfc2_b[0]);
+    }
+}
 }  // namespace
 
 // The same tail for ANY board (Go 9x9 / 19x19), trunk output in NCHW, in two kernels that read the board count from device
@@ -732,6 +843,20 @@ extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* h
     if (H > 8 || W > 8 || PC * H * W > TAIL_MAXIN || A > TAIL_MAXA || HID > TAIL_HID || VC * H * W > 64) return -1;
     const dim3 grid((unsigned)((batch + TAIL_NB - 1) / TAIL_NB)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_mfma_tail = getenv("SPRL_TAIL_NO_MFMA") != nullptr;    // lab: the round-2 FC stage
+    if (maps_in && !no_mfma_tail) {                    // FC layers only: on the matrix cores, 64 boards per workgroup
+        const int PIN = PC * H * W, VIN = VC * H * W;
+        const size_t lds = (size_t)(4 * ((PIN + 3) / 4) * TFC_LDW + 4 * ((VIN + 3) / 4) * TFC_LDW + TFC_NB * TFC_LDM + TFC_LDW + 128) * sizeof(float);
+        if (PIN + 4 * ((VIN + 3) / 4) > TFC_LDM || 4 * ((PIN + 3) / 4) > TFC_LDM) return -1;      // (the padded contraction stays inside a map row)
+        static bool attr_set = false;                  // more than the 64 KB a kernel gets by default
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)tail_fc_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return -2;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tail_fc_mfma_kernel, dim3((unsigned)((batch + TFC_NB - 1) / TFC_NB)), block, lds, st, maps_in, pfc_w, pfc_b,
+                           vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits, value, batch, PIN, VIN, A, HID, batch_dev);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (PC == 2 && VC == 1)
         hipLaunchKernelGGL((tail_kernel<2, 1>), grid, block, 0, st, x, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits,
                            value, batch, H, W, A, HID, batch_dev, maps_in);
