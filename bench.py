@@ -432,6 +432,39 @@ def main():
     if pops > 1 and not args.no_profile and not args.no_alone_pass and args.game == "othello":     # (a Go step is minutes long)
         M1 = measure(1, 1, 0)
 
+    def alone_sample(rounds, warm):
+        """Go configurations: a BOUNDED one-population sample instead of a whole extra step - one engine with the resident games of
+        one population (the launch geometry of the timed run), `warm` search rounds untimed, then `rounds` rounds.  Same dict as
+        measure(); games are between move warm / 100 and (warm + rounds) / 100 (a move is num_traversals / max_queue rounds)."""
+        cfg = E.default_config(G["engine"], lib, device=local_rank, concurrent_games=args.concurrent // pops,
+                               num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap, stream_base=stream_cursor[0],
+                               profile=1, own_stream=0, resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
+        stream_cursor[0] += 2 * (games // pops)
+        en = E.Engine(cfg, lib)
+        en.set_model(model_path if model_path else args.model)
+        en.begin(args.concurrent // pops)
+        done = 0
+        while done < warm:
+            en.step(min(args.rounds_per_call, warm - done))
+            done += min(args.rounds_per_call, warm - done)
+        st0 = {k: v for k, v in en.stats().items() if isinstance(v, (int, float))}
+        barrier()
+        t0 = time.perf_counter()
+        done = 0
+        while done < rounds:
+            en.step(min(args.rounds_per_call, rounds - done))
+            done += min(args.rounds_per_call, rounds - done)
+        st1 = {k: v for k, v in en.stats().items() if isinstance(v, (int, float))}
+        barrier()
+        elapsed = time.perf_counter() - t0
+        d = {k: st1[k] - st0[k] for k in st1 if k not in ("max_nodes_in_arena", "hbm_bytes")}
+        en.close()
+        return dict(pops=1, steps=0, elapsed=elapsed, d=d, st1=st1, tree_busy=None, tree_sum=None, conv_busy=None, conv_sum=None)
+
+    MA = None
+    if pops > 1 and not args.no_profile and not args.no_alone_pass and args.game != "othello" and model_path:
+        MA = alone_sample(1500 if args.game == "go9" else 600, 1500 if args.game == "go9" else 600)
+
     # what the collective backend really saw: world size, backend name and every rank's device, gathered from the ranks themselves
     me = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "name": torch.cuda.get_device_name(local_rank),
           "pid": os.getpid()}
@@ -496,6 +529,14 @@ def main():
                 "what": "the same workload with ONE population (no kernel of another stream beside it), one step, after the timed "
                         "region: per-launch figures comparable to the rocprofv3 averages under profiles/",
                 "games_per_sec": games * world / M1["elapsed"], "roofline": c1, "roofline_tree": t1}
+        if MA is not None:
+            ca, ta = rooflines(MA)
+            out["one_population_sample"] = {
+                "what": "the same kernels with ONE population (no kernel of another stream beside them, so a launch does not wait for "
+                        "CUs held by the other population's convolutions): a bounded sample after the timed region, one engine with "
+                        "the resident games of one population, the rounds given below - a whole extra step would take minutes",
+                "rounds": MA["d"]["rounds"], "rounds_before": MA["st1"]["rounds"] - MA["d"]["rounds"],
+                "seconds": MA["elapsed"], "roofline": ca, "roofline_tree": ta}
         if world == 1 and not args.no_cpu_baseline and args.game == "othello":
             mp_model = model_path
             if mp_model is None:

@@ -25,8 +25,8 @@ def measure(game, games, model, rounds, warm):
     s0 = eng.stats()
     t = time.time()
     eng.step(rounds)
+    s1 = eng.stats()                           # (reads the device counters: waits for the rounds just queued)
     dt = time.time() - t
-    s1 = eng.stats()
     d = {k: s1[k] - s0[k] for k in ("traversals", "expansions", "plies", "nn_evals", "kernel_launches")}
     info = eng.evaluator_info()
     eng.close()
