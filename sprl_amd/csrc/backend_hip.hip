@@ -76,6 +76,8 @@ __global__ void __launch_bounds__(1024) leaf_scan_kernel(const uint32_t* count, 
     if (t == 1023) {
         counters->leaf_total = part[1023];
         counters->leaf_rows += part[1023];
+        counters->active_last = counters->active_slots;     // (the step kernel has finished: this launch follows it on its stream)
+        counters->active_slots = 0;
     }
 }
 

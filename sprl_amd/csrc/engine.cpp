@@ -582,7 +582,9 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
     Counters c;
     memset(&c, 0, sizeof(c));
     for (int r = 0; r < launches; ++r) {
-        be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
+        // network rounds: the leaf scan behind the step kernel moves active_slots to active_last and clears it (one launch less
+        // per round); the chained rounds of the in-kernel evaluators have no scan
+        if (!net) be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
         void* k0 = e->cfg.profile ? be::mark() : nullptr;
         if (be::launch_step(e->cfg.game, P) != 0) return fail(SPRL_E_DEVICE, be::last_error());
         if (e->cfg.profile) {
@@ -613,6 +615,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
                 e->nn_batches++;
                 if ((r & 7) == 7 || r == launches - 1) {
                     if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+                    c.active_slots = c.active_last;
                     e->nn_rows += (int64_t)(c.leaf_rows - e->last_leaf_rows);
                     e->last_leaf_rows = c.leaf_rows;
                     if (c.error != ERR_NONE) break;
@@ -622,6 +625,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
                 continue;
             }
             if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+            c.active_slots = c.active_last;
             if (c.error != ERR_NONE) break;
             const int bucket = e->nn_bucket;
             int batch = (int)((c.leaf_total + (uint32_t)bucket - 1) / (uint32_t)bucket) * bucket;
@@ -922,10 +926,11 @@ int sprl_match_play(const sprl_config* cfg, const sprl_match_agent* agent0, cons
     for (int64_t it = 0;; ++it) {
         if (it > launch_cap) return done(fail(SPRL_E_STATE, "match did not finish within its launch bound"));
         P.launch_seq = (uint32_t)(it + 1);
-        be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
+        if (!any_net) be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));      // (with a network: cleared by the leaf scan)
         if (be::launch_match(c.game, P) != 0) return done(fail(SPRL_E_DEVICE, be::last_error()));
         if (any_net && be::launch_compact(P, floats_per_leaf) != 0) return done(fail(SPRL_E_DEVICE, be::last_error()));
         if (be::sync() != 0 || be::d2h(&cn, P.counters, sizeof(cn)) != 0) return done(fail(SPRL_E_DEVICE, be::last_error()));
+        if (any_net) cn.active_slots = cn.active_last;
         if (cn.error != ERR_NONE) return done(check_device_error(e, cn));
         if (any_net && cn.leaf_total > 0) {
             // rows [0, split) belong to agent 0's trees, [split, total) to agent 1's: one forward per agent

@@ -94,6 +94,8 @@ struct Counters {
     uint32_t active_slots;  // slots still holding an unfinished game after the last step
     uint32_t leaf_total;    // leaves queued for the network by the last step (dense batch size)
     unsigned long long leaf_rows;   // running sum of leaf_total over the launches of a run (rows evaluated by the network)
+    uint32_t active_last;   // network rounds: active_slots of the last step, moved here by the leaf scan, which also clears
+    uint32_t pad_;          // active_slots for the next step (no separate memset launch per round)
 };
 
 struct alignas(32) Mailbox {   // match play: the move a side has just made, handed to the partner tree of the same game

@@ -95,6 +95,8 @@ int launch_compact(const EngineParams& P, int floats_per_leaf) {
     }
     P.counters->leaf_total = run;
     P.counters->leaf_rows += run;
+    P.counters->active_last = P.counters->active_slots;
+    P.counters->active_slots = 0;
     return 0;
 }
 int launch_records_scan(const EngineParams& P) {
