@@ -750,10 +750,27 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     };
     // rotated by one K step like the 8x8 kernel's loop: K step 0 runs before the loop, an iteration is {K step 2c+1, V(c+1),
     // chunk c+2 to LDS, request chunk c+3 (DEEP: c+4), barrier, K step 2c+2}
+    // layout T: the residual rows of the first output band are requested while the last K steps still run (the activation
+    // registers are dead by then) - at the point behind which no filter quad is requested any more, so that nothing the K loop
+    // waits for queues up behind these HBM loads: DEEP after K step 13, otherwise before K step 15
+    constexpr int NR_T = M == 4 ? 2 : M;               // rows per output band (see the output stage)
+    constexpr bool EARLY_RES = RES && LAY == 1;
+    const int q_out = 4 * kb + c_sub;                  // layout T: this lane's output channels 4 q_out .. 4 q_out + 3
+    const int obase = (LAY == 1 && t_n >= 0) ? ((t_n * 16 + q_out) * MC * TPB + t_tt) * 16 : OOB;
+    f4 rv0[EARLY_RES ? NR_T * M : 1];
+    auto early_res = [&]() {
+        if constexpr (EARLY_RES) {
+#pragma unroll
+            for (int cc = 0; cc < NR_T * M; ++cc)
+                rv0[cc] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + cc * TPB * 16, 0, 0));
+        }
+    };
     auto phase = [&](int c, float* pre) {
         const float* vs = v_buf + (c & 1) * 2 * VG;
+        if (EARLY_RES && !DEEP && c == 7) early_res();
         kstep(vs + VG, 2 * c + 1, std::false_type{}, DEEP ? a1 : a0);
         __builtin_amdgcn_sched_barrier(0);
+        if (EARLY_RES && DEEP && c == 6) early_res();
         if (c + 1 < 8) produce(c + 1);
         if (c + 2 < 8) {
             lstore(in_buf + (c & 1) * IN_BUF, pre);
@@ -790,9 +807,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
 
     if constexpr (LAY == 1) {
         // ---- layout T: inverse transform per row band, the four channels of a cell leave as one 16-byte vector ----
-        constexpr int NR = M == 4 ? 2 : M;             // rows per band: M = 3 one band of the whole tile, M = 4 two bands of two rows
-        const int q_out = 4 * kb + c_sub;              // this lane's output channels: 4 q_out .. 4 q_out + 3  (component r)
-        const int obase = t_n >= 0 ? ((t_n * 16 + q_out) * MC * TPB + t_tt) * 16 : OOB;
+        constexpr int NR = NR_T;                       // rows per band: M = 3 one band of the whole tile, M = 4 two bands of two rows
         const f4 sc4 = *(const f4*)(scale + 4 * q_out), sh4 = *(const f4*)(shift + 4 * q_out);
         const float relu_floor = relu ? 0.0f : -__builtin_inff();
 #pragma unroll
@@ -800,8 +815,10 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
             f4 outv[NR * M], rv[NR * M];
             if (RES) {
 #pragma unroll
-                for (int c = 0; c < NR * M; ++c)
-                    rv[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + (band * NR * M + c) * TPB * 16, 0, 0));
+                for (int c = 0; c < NR * M; ++c) {
+                    if (band == 0) rv[c] = rv0[EARLY_RES ? c : 0];      // (requested during the last K steps)
+                    else rv[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + (band * NR * M + c) * TPB * 16, 0, 0));
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
