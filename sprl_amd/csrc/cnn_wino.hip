@@ -281,20 +281,26 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // DESIGN.md section 5): 227.8 us against 212.7 us - more streams do not help either.  What the PMC says instead: the filter
     // stream is 11.7 TB/s of L2-to-CU traffic, two thirds of the practical L2 rate, at an L2 latency of 271 cycles - a bandwidth,
     // not a latency (tools/conv_pmc.sh, profiles/r03z_conv_pmc_*).)
-    auto phase = [&](int c) {
-        const float* vs = v_buf + (c & 1) * 2 * V_G2;
-        if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
-        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{});
-        if (c + 1 < 8) produce(c + 1);
-        __syncthreads();
-        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G2, 2 * c + 2, -1, std::false_type{});
-    };
-
     f4 rres[4][4];
     auto rload = [&](int r) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, 2));
+    };
+    auto phase = [&](int c) {
+        const float* vs = v_buf + (c & 1) * 2 * V_G2;
+        if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
+        // the first residual rows are requested before the LAST K step: the activation registers are dead, no filter quad is
+        // requested behind them any more (nothing the K loop waits for queues up behind these HBM loads), and the output stage
+        // finds them there one K step later
+        if (RES && c == 7) {
+            rload(0);
+            rload(1);
+        }
+        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{});
+        if (c + 1 < 8) produce(c + 1);
+        __syncthreads();
+        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G2, 2 * c + 2, -1, std::false_type{});
     };
 
     {   // the first two chunks are requested together: one HBM round trip before the first V can be built, not two
@@ -324,10 +330,6 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         return;
     }
 #endif
-    if (RES) {
-        rload(0);
-        rload(1);
-    }
     const float relu_floor = relu ? 0.0f : -__builtin_inff();      // ReLU as one v_max against a scalar (no select per element)
     constexpr int OC = 3;                              // HEADS: 2 policy + 1 value head channels
     float hp[HEADS ? OC : 1][4][4];                    // HEADS: this lane's share of the 1x1 head convolutions (its 4 channels)
