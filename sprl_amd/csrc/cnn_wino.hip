@@ -293,6 +293,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         // the first residual rows are requested before the LAST K step: the activation registers are dead, no filter quad is
         // requested behind them any more (nothing the K loop waits for queues up behind these HBM loads), and the output stage
         // finds them there one K step later
+        // (rows 0-2 there and row 3 behind the first component were measured too: the third row costs registers in the last
+        // phases - 203.0 -> 208.6 us, 426.7 -> 410 games/s.)
         if (RES && c == 7) {
             rload(0);
             rload(1);
