@@ -306,6 +306,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     };
 
     {   // the first two chunks are requested together: one HBM round trip before the first V can be built, not two
+        // (chunk 2 requested here as well, behind the filter quads of K step 0 and into registers of its own, was measured at the
+        // end of round 3: 203.0 -> 209.0 us; earlier in the round in front of them: 1-2 % slower too)
         f4 first[2];
         gload_to(0, first);
         gload_to(1, pre);
@@ -784,18 +786,22 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * VG, 2 * c + 2, std::false_type{}, a0);
     };
 
-    gload(0, pre0);
-    lstore(in_buf, pre0);
-    gload(1, pre0);
+    {   // chunks 0 and 1 are requested together into registers of their own (no accumulator is live yet): one trip to HBM before
+        // the first V can be built, not two; the chunks of the later phases go out behind the filter quads of the first K steps
+        float c0[LAY ? 4 * NPC : NLD], c1[LAY ? 4 * NPC : NLD];
+        gload(0, c0);
+        gload(1, c1);
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) aload(0, k, a0);
-    if (DEEP) {
+        for (int k = 0; k < NQ; ++k) aload(0, k, a0);
+        if (DEEP) {
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) aload(1, k, a1);
+            for (int k = 0; k < NQ; ++k) aload(1, k, a1);
+        }
+        gload(2, pre0);
+        if (DEEP_ACT) gload(3, pre1);
+        lstore(in_buf, c0);
+        lstore(in_buf + IN_BUF, c1);
     }
-    lstore(in_buf + IN_BUF, pre0);
-    gload(2, pre0);
-    if (DEEP_ACT) gload(3, pre1);
     __syncthreads();
     produce(0);
     __syncthreads();
