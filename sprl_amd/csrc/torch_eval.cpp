@@ -88,25 +88,63 @@ busy::Log g_conv_busy;
 
 struct ConvProfile {
     bool on = false;
-    std::vector<hipEvent_t> ev;          // pairs, resolved lazily
+    std::vector<hipEvent_t> ev;          // pairs (start, end), resolved lazily
+    std::vector<uint8_t> end_shared;     // per pair: its end event is also the next pair's start (consecutive launches of a forward)
+    hipEvent_t last_end = nullptr;       // end event of the last timed launch, while it may still become the next one's start
     double ms = 0.0;
     int64_t launches = 0, boards = 0;
     busy::Chain chain;                   // the same intervals on the process-wide clock (several models on several streams)
+    // Start of a timed launch.  `chained`: nothing was queued on the stream since the previous timed launch of this forward, so
+    // that launch's end event marks this one's start as well - an event record is a packet of its own in the hardware queue, and
+    // two per convolution cost the bench 4 % (round 3: 442.9 games/s without the events, 426 with them).
+    hipEvent_t begin(hipStream_t st, bool chained) {
+        if (!on) return nullptr;
+        if (chained && last_end && !end_shared.empty()) {
+            end_shared.back() = 1;
+            hipEvent_t e = last_end;
+            last_end = nullptr;
+            return e;
+        }
+        last_end = nullptr;
+        hipEvent_t e = busy::get_event();
+        if (e) (void)hipEventRecord(e, st);
+        return e;
+    }
+    void end(hipEvent_t e0, hipStream_t st, int64_t nboards) {
+        if (!e0) return;
+        hipEvent_t e1 = busy::get_event();
+        if (!e1) {                       // out of events: this launch goes untimed (a shared start stays with the pair before it)
+            if (end_shared.empty() || !end_shared.back()) busy::put_event(e0);
+            else end_shared.back() = 0;
+            return;
+        }
+        (void)hipEventRecord(e1, st);
+        ev.push_back(e0);
+        ev.push_back(e1);
+        end_shared.push_back(0);
+        last_end = e1;
+        launches++;
+        boards += nboards;
+        if (ev.size() >= 8192) resolve();
+    }
     void resolve() {
         std::vector<std::pair<double, double>> iv;
         iv.reserve(ev.size() / 2);
         for (size_t i = 0; i + 1 < ev.size(); i += 2) {
             double t = 0.0;
             (void)hipEventSynchronize(ev[i + 1]);
-            iv.push_back(chain.resolve(ev[i], ev[i + 1], &t));
+            iv.push_back(chain.resolve(ev[i], ev[i + 1], &t));      // (takes the start event; a shared end is the next pair's start)
             ms += t;
-            busy::put_event(ev[i + 1]);
+            if (!end_shared[i / 2]) busy::put_event(ev[i + 1]);
         }
         ev.clear();
+        end_shared.clear();
+        last_end = nullptr;              // (it went back to the pool: the next launch records its own start)
         g_conv_busy.add(iv);
     }
     ~ConvProfile() {
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        for (size_t i = 0; i < ev.size(); ++i)
+            if (!((i & 1) == 0 && i >= 2 && end_shared[i / 2 - 1])) (void)hipEventDestroy(ev[i]);      // a shared event appears twice
         chain.release();
     }
 };
@@ -254,21 +292,14 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
     if (sprl_stem_conv3x3_w(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
                             n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, batch_dev, stream) != 0)
         return false;
+    bool chained = false;
     auto conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
                     at::Tensor& dst) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
-        if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
+        hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, chained) : nullptr;
+        chained = true;                              // the convolutions of a forward follow each other on the stream
         const int rc = sprl_wino_conv64_dev(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(),
                                             res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, stream);
-        if (timed) {
-            (void)hipEventRecord(e1, (hipStream_t)stream);
-            prof->ev.push_back(e0);
-            prof->ev.push_back(e1);
-            prof->launches++;
-            prof->boards += B;
-            if (prof->ev.size() >= 8192) prof->resolve();
-        }
+        if (prof) prof->end(e0, (hipStream_t)stream, B);
         return rc == 0;
     };
     const int A0 = (int)n.pfc_w.size(1), HID0 = (int)n.vfc1_w.size(1);
@@ -279,22 +310,14 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
         const auto& b = n.blocks[bi];
         if (!conv(x, b.u1, b.s1, b.t1, nullptr, y)) return false;
         if (fuse_last && bi + 1 == n.blocks.size()) {
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
-            if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
+            hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, chained) : nullptr;
             // last convolution + both head convolutions in one kernel (the trunk output is never written), then the FC layers
             at::Tensor maps = mdl->maps;
             const int rc = sprl_wino_conv64_heads(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(),
                                                   b.t2.data_ptr<float>(), x.data_ptr<float>(), B, H, W, batch_dev,
                                                   n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), maps.data_ptr<float>(),
                                                   stream);
-            if (timed) {
-                (void)hipEventRecord(e1, (hipStream_t)stream);
-                prof->ev.push_back(e0);
-                prof->ev.push_back(e1);
-                prof->launches++;
-                prof->boards += B;
-            }
+            if (prof) prof->end(e0, (hipStream_t)stream, B);
             if (rc != 0) return false;
             if (sprl_tail_fc(nullptr, maps.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
                              n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
@@ -373,20 +396,13 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
     if (sprl_stem_conv3x3_t(planes, n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(), n.stem_shift.data_ptr<float>(), x, cap, P, H, W,
                             tile, batch_dev, stream) != 0)
         return false;
+    bool chained_t = false;
     auto conv = [&](const float* src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res, float* dst) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
-        if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
+        hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, chained_t) : nullptr;
+        chained_t = true;
         const int rc = sprl_wino_conv64_t(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1, tile,
                                           batch_dev, stream);
-        if (timed) {
-            (void)hipEventRecord(e1, (hipStream_t)stream);
-            prof->ev.push_back(e0);
-            prof->ev.push_back(e1);
-            prof->launches++;
-            prof->boards += cap;
-            if (prof->ev.size() >= 8192) prof->resolve();
-        }
+        if (prof) prof->end(e0, (hipStream_t)stream, cap);
         return rc == 0;
     };
     for (const auto& b : n.blocks) {
@@ -440,19 +456,10 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
         auto timed_conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
                               at::Tensor& dst) {
             const int B0 = (int)src.size(0);
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            const bool timed = prof && prof->on && (e0 = busy::get_event()) && (e1 = busy::get_event());
-            if (timed) (void)hipEventRecord(e0, (hipStream_t)stream);
+            hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, false) : nullptr;      // (other kernels sit between these launches)
             const int rc = sprl_wino_conv64_nchw(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res,
                                                  dst.data_ptr<float>(), B0, H0, W0, 1, stream);
-            if (timed) {
-                (void)hipEventRecord(e1, (hipStream_t)stream);
-                prof->ev.push_back(e0);
-                prof->ev.push_back(e1);
-                prof->launches++;
-                prof->boards += B0;
-                if (prof->ev.size() >= 8192) prof->resolve();
-            }
+            if (prof) prof->end(e0, (hipStream_t)stream, B0);
             return rc == 0;
         };
         for (const auto& b : n.blocks) {
