@@ -89,42 +89,40 @@ busy::Log g_conv_busy;
 struct ConvProfile {
     bool on = false;
     std::vector<hipEvent_t> ev;          // pairs (start, end), resolved lazily
-    std::vector<uint8_t> end_shared;     // per pair: its end event is also the next pair's start (consecutive launches of a forward)
-    hipEvent_t last_end = nullptr;       // end event of the last timed launch, while it may still become the next one's start
     double ms = 0.0;
     int64_t launches = 0, boards = 0;
     busy::Chain chain;                   // the same intervals on the process-wide clock (several models on several streams)
-    // Start of a timed launch.  `chained`: nothing was queued on the stream since the previous timed launch of this forward, so
-    // that launch's end event marks this one's start as well - an event record is a packet of its own in the hardware queue, and
-    // two per convolution cost the bench 4 % (round 3: 442.9 games/s without the events, 426 with them).
-    hipEvent_t begin(hipStream_t st, bool chained) {
-        if (!on) return nullptr;
-        if (chained && last_end && !end_shared.empty()) {
-            end_shared.back() = 1;
-            hipEvent_t e = last_end;
-            last_end = nullptr;
-            return e;
-        }
-        last_end = nullptr;
-        hipEvent_t e = busy::get_event();
-        if (e) (void)hipEventRecord(e, st);
-        return e;
+    // The trunk convolutions of a forward follow each other on the stream with nothing between them, so ONE pair of events brackets
+    // all of them (open before the first, note per launch, close behind the last): an event record is a packet of its own in the
+    // hardware queue, and two per convolution cost the bench 4 % (round 3: 442.9 games/s without the events, 426 with them).
+    hipEvent_t open_ev = nullptr;
+    int64_t open_launches = 0, open_boards = 0;
+    void open(hipStream_t st) {
+        if (!on) return;
+        if (open_ev) busy::put_event(open_ev);       // (a forward that failed half way)
+        open_ev = busy::get_event();
+        if (open_ev) (void)hipEventRecord(open_ev, st);
+        open_launches = open_boards = 0;
     }
-    void end(hipEvent_t e0, hipStream_t st, int64_t nboards) {
-        if (!e0) return;
-        hipEvent_t e1 = busy::get_event();
-        if (!e1) {                       // out of events: this launch goes untimed (a shared start stays with the pair before it)
-            if (end_shared.empty() || !end_shared.back()) busy::put_event(e0);
-            else end_shared.back() = 0;
+    void note(int64_t nboards) {
+        if (!open_ev) return;
+        open_launches++;
+        open_boards += nboards;
+    }
+    void close(hipStream_t st) {
+        if (!open_ev) return;
+        hipEvent_t e1 = open_launches ? busy::get_event() : nullptr;
+        if (!e1) {
+            busy::put_event(open_ev);
+            open_ev = nullptr;
             return;
         }
         (void)hipEventRecord(e1, st);
-        ev.push_back(e0);
+        ev.push_back(open_ev);
         ev.push_back(e1);
-        end_shared.push_back(0);
-        last_end = e1;
-        launches++;
-        boards += nboards;
+        open_ev = nullptr;
+        launches += open_launches;
+        boards += open_boards;
         if (ev.size() >= 8192) resolve();
     }
     void resolve() {
@@ -133,18 +131,16 @@ struct ConvProfile {
         for (size_t i = 0; i + 1 < ev.size(); i += 2) {
             double t = 0.0;
             (void)hipEventSynchronize(ev[i + 1]);
-            iv.push_back(chain.resolve(ev[i], ev[i + 1], &t));      // (takes the start event; a shared end is the next pair's start)
+            iv.push_back(chain.resolve(ev[i], ev[i + 1], &t));
             ms += t;
-            if (!end_shared[i / 2]) busy::put_event(ev[i + 1]);
+            busy::put_event(ev[i + 1]);
         }
         ev.clear();
-        end_shared.clear();
-        last_end = nullptr;              // (it went back to the pool: the next launch records its own start)
         g_conv_busy.add(iv);
     }
     ~ConvProfile() {
-        for (size_t i = 0; i < ev.size(); ++i)
-            if (!((i & 1) == 0 && i >= 2 && end_shared[i / 2 - 1])) (void)hipEventDestroy(ev[i]);      // a shared event appears twice
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (open_ev) (void)hipEventDestroy(open_ev);
         chain.release();
     }
 };
@@ -292,14 +288,12 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
     if (sprl_stem_conv3x3_w(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
                             n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, batch_dev, stream) != 0)
         return false;
-    bool chained = false;
+    if (prof) prof->open((hipStream_t)stream);       // one event pair around all the trunk convolutions of this forward
     auto conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
                     at::Tensor& dst) {
-        hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, chained) : nullptr;
-        chained = true;                              // the convolutions of a forward follow each other on the stream
         const int rc = sprl_wino_conv64_dev(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(),
                                             res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, stream);
-        if (prof) prof->end(e0, (hipStream_t)stream, B);
+        if (prof) prof->note(B);
         return rc == 0;
     };
     const int A0 = (int)n.pfc_w.size(1), HID0 = (int)n.vfc1_w.size(1);
@@ -310,14 +304,16 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
         const auto& b = n.blocks[bi];
         if (!conv(x, b.u1, b.s1, b.t1, nullptr, y)) return false;
         if (fuse_last && bi + 1 == n.blocks.size()) {
-            hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, chained) : nullptr;
             // last convolution + both head convolutions in one kernel (the trunk output is never written), then the FC layers
             at::Tensor maps = mdl->maps;
             const int rc = sprl_wino_conv64_heads(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(),
                                                   b.t2.data_ptr<float>(), x.data_ptr<float>(), B, H, W, batch_dev,
                                                   n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), maps.data_ptr<float>(),
                                                   stream);
-            if (prof) prof->end(e0, (hipStream_t)stream, B);
+            if (prof) {
+                prof->note(B);
+                prof->close((hipStream_t)stream);
+            }
             if (rc != 0) return false;
             if (sprl_tail_fc(nullptr, maps.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
                              n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
@@ -330,6 +326,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
         if (!conv(y, b.u2, b.s2, b.t2, x.data_ptr<float>(), z)) return false;
         std::swap(x, z);
     }
+    if (prof) prof->close((hipStream_t)stream);
     const int HW = H * W;
     const int A = (int)n.pfc_w.size(1), HID = (int)n.vfc1_w.size(1);
     if (logits_out && value_out && n.vfc2_w.numel() == HID &&
@@ -396,19 +393,18 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
     if (sprl_stem_conv3x3_t(planes, n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(), n.stem_shift.data_ptr<float>(), x, cap, P, H, W,
                             tile, batch_dev, stream) != 0)
         return false;
-    bool chained_t = false;
+    if (prof) prof->open((hipStream_t)stream);       // one event pair around all the trunk convolutions of this forward
     auto conv = [&](const float* src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res, float* dst) {
-        hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, chained_t) : nullptr;
-        chained_t = true;
         const int rc = sprl_wino_conv64_t(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1, tile,
                                           batch_dev, stream);
-        if (prof) prof->end(e0, (hipStream_t)stream, cap);
+        if (prof) prof->note(cap);
         return rc == 0;
     };
     for (const auto& b : n.blocks) {
         if (!conv(x, b.u1t, b.s1, b.t1, nullptr, ya) || !conv(ya, b.u2t, b.s2, b.t2, x, za)) return false;
         std::swap(x, za);
     }
+    if (prof) prof->close((hipStream_t)stream);
     return sprl_tail_t(x, n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(),
                        n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(), n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(),
                        mdl->npmaps.data_ptr<float>(), logits_out, value_out, cap, H, W, n.pc, n.vc, A, HID, tile, batch_dev, stream) == 0;
@@ -456,10 +452,13 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
         auto timed_conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
                               at::Tensor& dst) {
             const int B0 = (int)src.size(0);
-            hipEvent_t e0 = prof ? prof->begin((hipStream_t)stream, false) : nullptr;      // (other kernels sit between these launches)
+            if (prof) prof->open((hipStream_t)stream);      // (other kernels sit between these launches: a pair per launch)
             const int rc = sprl_wino_conv64_nchw(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res,
                                                  dst.data_ptr<float>(), B0, H0, W0, 1, stream);
-            if (prof) prof->end(e0, (hipStream_t)stream, B0);
+            if (prof) {
+                prof->note(B0);
+                prof->close((hipStream_t)stream);
+            }
             return rc == 0;
         };
         for (const auto& b : n.blocks) {
