@@ -10,6 +10,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace {
 template <bool RESIDUAL>
 __global__ void __launch_bounds__(256) bn_relu_kernel(float4* __restrict__ x, const float4* __restrict__ res,
@@ -709,12 +711,13 @@ __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __r
     }
 }
 
+// valu != 0: the VALU form (a lab / test variant; it cannot read the count from the device or write layout T)
 static int stem_any_board(const float* planes, const float* w, const float* scale, const float* shift, float* y, long long batch, int P,
-                          int H, int W, const unsigned* batch_dev, int tile_m, void* stream) {
+                          int H, int W, const unsigned* batch_dev, int tile_m, int valu, void* stream) {
     if (batch <= 0) return 0;
     const long long cells = batch * H * W;
     if ((batch_dev || tile_m) && (cells * P * 4 >= 0x40000000LL || (P != 3 && P != 17))) return -1;   // only the MFMA form does these
-    if (cells * P * 4 < 0x40000000LL && (batch_dev || tile_m || !getenv("SPRL_STEM_VALU"))) {
+    if (cells * P * 4 < 0x40000000LL && (batch_dev || tile_m || !valu)) {
         long long blocks = (cells / 16 + 3) / 4;
         if (blocks > 256 * 6) blocks = 256 * 6;        // grid-stride over 16-cell tiles: the weight fragments are staged once per workgroup
         if (blocks < 1) blocks = 1;
@@ -732,25 +735,31 @@ static int stem_any_board(const float* planes, const float* w, const float* scal
 }
 extern "C" int sprl_stem_conv3x3_nchw_dev(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                           long long batch, int P, int H, int W, const unsigned* batch_dev, void* stream) {
-    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, batch_dev, 0, stream);
+    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, batch_dev, 0, 0, stream);
 }
 extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                       long long batch, int P, int H, int W, void* stream) {
-    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, nullptr, 0, stream);
+    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, nullptr, 0, 0, stream);
+}
+// the VALU form of the same stem (tests, lab): no environment switch picks it, only this entry point
+extern "C" int sprl_stem_conv3x3_nchw_valu(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                           long long batch, int P, int H, int W, void* stream) {
+    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, nullptr, 0, 1, stream);
 }
 // the same stem writing layout T (tile = 3 or 4) for the any-board trunk kernel
 extern "C" int sprl_stem_conv3x3_t(const float* planes, const float* w, const float* scale, const float* shift, float* y,
                                    long long batch, int P, int H, int W, int tile, const unsigned* batch_dev, void* stream) {
     if (tile != 3 && tile != 4) return -1;
-    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, batch_dev, tile, stream);
+    return stem_any_board(planes, w, scale, shift, y, batch, P, H, W, batch_dev, tile, 0, stream);
 }
 
-extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
-                                   int batch, int P, int H, int W, const unsigned* batch_dev, void* stream) {
+// valu != 0: the VALU form also for 3 planes (lab / test variant)
+extern "C" int sprl_stem_conv3x3_w_form(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                        int batch, int P, int H, int W, int valu, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     if (H > 8 || W > 8) return -1;
     const dim3 grid((unsigned)((batch + 3) / 4)), block(256);
-    if (P == 3 && !getenv("SPRL_STEM_VALU")) {
+    if (P == 3 && !valu) {
         int blocks = (batch + 3) / 4;
         if (blocks > 256 * 8) blocks = 256 * 8;        // grid-stride over boards: the weight fragments are loaded once per wave
         hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)blocks), block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W,
@@ -759,6 +768,10 @@ extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const fl
     else if (P == 17) hipLaunchKernelGGL(stem_kernel<17>, grid, block, 0, (hipStream_t)stream, planes, w, scale, shift, y, batch, H, W, batch_dev);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int sprl_stem_conv3x3_w(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                   int batch, int P, int H, int W, const unsigned* batch_dev, void* stream) {
+    return sprl_stem_conv3x3_w_form(planes, w, scale, shift, y, batch, P, H, W, 0, batch_dev, stream);
 }
 
 // board_w > 0: x is in layout W (cnn_wino.hip; needs C == 64), board_w == 0: NCHW
@@ -823,6 +836,10 @@ extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* h
                             const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
                             float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
                             const unsigned* batch_dev, void* stream);
+extern "C" int sprl_tail_fc_form(const float* x, const float* maps_in, const float* hw, const float* hb, const float* pfc_w,
+                                 const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                                 float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID, int no_mfma,
+                                 const unsigned* batch_dev, void* stream);
 
 // x: trunk output in layout W; hw/hb: [PC + VC][64] / [PC + VC] head convolutions (policy rows first); pfc_w: [PC*H*W][A]
 // (transposed Linear weight), vfc1_w: [VC*H*W][HID], vfc2_w: [HID]; logits: [batch][A], value: [batch].  -1: shape not covered.
@@ -839,19 +856,45 @@ extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* h
                             const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
                             float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
                             const unsigned* batch_dev, void* stream) {
+    return sprl_tail_fc_form(x, maps_in, hw, hb, pfc_w, pfc_b, vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits, value, batch, H, W, PC, VC, A, HID, 0,
+                             batch_dev, stream);
+}
+
+// LDS the MFMA FC tail needs for a shape (bytes); the launcher raises the kernel's dynamic-LDS limit to TFC_LDS_LIMIT on every
+// device it launches on and refuses shapes above it
+constexpr size_t TFC_LDS_LIMIT = 128 * 1024;
+extern "C" long long sprl_tail_fc_lds_bytes(int PIN, int VIN) {
+    return (long long)(4 * ((PIN + 3) / 4) * TFC_LDW + 4 * ((VIN + 3) / 4) * TFC_LDW + TFC_NB * TFC_LDM + TFC_LDW + 128) * (long long)sizeof(float);
+}
+extern "C" long long sprl_tail_fc_lds_limit(void) { return (long long)TFC_LDS_LIMIT; }
+
+// no_mfma != 0: the scalar FC stage of round 2 (lab variant)
+extern "C" int sprl_tail_fc_form(const float* x, const float* maps_in, const float* hw, const float* hb, const float* pfc_w,
+                                 const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                                 float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID, int no_mfma,
+                                 const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     if (H > 8 || W > 8 || PC * H * W > TAIL_MAXIN || A > TAIL_MAXA || HID > TAIL_HID || VC * H * W > 64) return -1;
     const dim3 grid((unsigned)((batch + TAIL_NB - 1) / TAIL_NB)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    static const bool no_mfma_tail = getenv("SPRL_TAIL_NO_MFMA") != nullptr;    // lab: the round-2 FC stage
-    if (maps_in && !no_mfma_tail) {                    // FC layers only: on the matrix cores, 64 boards per workgroup
+    if (maps_in && !no_mfma) {                         // FC layers only: on the matrix cores, 64 boards per workgroup
         const int PIN = PC * H * W, VIN = VC * H * W;
-        const size_t lds = (size_t)(4 * ((PIN + 3) / 4) * TFC_LDW + 4 * ((VIN + 3) / 4) * TFC_LDW + TFC_NB * TFC_LDM + TFC_LDW + 128) * sizeof(float);
+        const size_t lds = (size_t)sprl_tail_fc_lds_bytes(PIN, VIN);
         if (PIN + 4 * ((VIN + 3) / 4) > TFC_LDM || 4 * ((PIN + 3) / 4) > TFC_LDM) return -1;      // (the padded contraction stays inside a map row)
-        static bool attr_set = false;                  // more than the 64 KB a kernel gets by default
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)tail_fc_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return -2;
-            attr_set = true;
+        if (lds > TFC_LDS_LIMIT) return -1;
+        // more than the 64 KB a kernel gets by default.  The attribute is PER DEVICE: one flag per device, set under a
+        // mutex - engines on several devices, or several host threads (--populations), all find it set for their device.
+        {
+            static std::mutex mu;
+            static bool attr_set[64] = { false };
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -2;
+            std::lock_guard<std::mutex> lock(mu);
+            if (!attr_set[dev]) {
+                if (hipFuncSetAttribute((const void*)tail_fc_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TFC_LDS_LIMIT) != hipSuccess)
+                    return -2;
+                attr_set[dev] = true;
+            }
         }
         hipLaunchKernelGGL(tail_fc_mfma_kernel, dim3((unsigned)((batch + TFC_NB - 1) / TFC_NB)), block, lds, st, maps_in, pfc_w, pfc_b,
                            vfc1_w, vfc1_b, vfc2_w, vfc2_b, logits, value, batch, PIN, VIN, A, HID, batch_dev);

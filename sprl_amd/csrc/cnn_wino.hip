@@ -107,11 +107,20 @@ __device__ __forceinline__ void inverse_transform_pair(const f2 (&m)[6][6], floa
     }
 }
 
-// head convolutions fused behind the last trunk convolution (HEADS = 1: 2 policy + 1 value head channels)
+// head convolutions fused behind the last trunk convolution (HEADS >= 1: 2 policy + 1 value head channels)
 struct HeadArgs {
     const float *hw, *hb;   // [3][64] weights (policy rows first), [3] biases
-    float* maps_out;        // ReLU'd head maps [batch][3 * H * W]; the FC layers run in sprl_tail_fc (cnn_epilogue.hip)
+    float* maps_out;        // HEADS = 1: ReLU'd head maps [batch][3 * H * W]; the FC layers run in sprl_tail_fc (cnn_epilogue.hip)
+    // HEADS = 2: the FC layers too (grid_networks.py:45,50-51) - the forward ends in this kernel, the maps never leave LDS
+    const float *pfc_w, *pfc_b;      // [2 * H * W][A] (transposed Linear weight), [A]
+    const float *vfc1_w, *vfc1_b;    // [H * W][HID], [HID]
+    const float *vfc2_w, *vfc2_b;    // [HID], [1]
+    float *logits, *value;           // [batch][A], [batch]
+    int A, HID;
 };
+// HEADS = 2 task split: the policy contraction (<= 128 long) in four parts, the hidden layer's (<= 64) in two; a task is one output
+// column x one part x the four boards of the workgroup, at most 32 weights long
+constexpr int FC_MAXA = 96, FC_LP = 32;
 
 #ifndef SPRL_WINO_DEEP4
 #define SPRL_WINO_DEEP4 0                             // 1: the F(4x4) layout-T kernel also keeps two activation chunks in flight
@@ -391,14 +400,73 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // (4 waves x 4 lane groups) are summed through LDS in a fixed order.  The LDS images are dead by now.
     constexpr int PROW = OC * 256 + 16;                // partial row stride: 32 lanes of a bank group -> 32 banks
     float* const part = lds;                           // [kb * 4 + c_sub][o][(i * 4 + j) * 16 + tl]
-    float* const maps = lds + 16 * PROW;               // [board][o * HW + row * W + col]
+    float* const maps = lds + 16 * PROW;               // HEADS = 1: [board][o * HW + row * W + col]; HEADS = 2: [o * HW + cell][board]
     constexpr int HW = H * W;
+    constexpr int PIN = 2 * HW, VIN = HW;
 #pragma unroll
     for (int oc = 0; oc < OC; ++oc)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[(kb * 4 + c_sub) * PROW + oc * 256 + (i * 4 + j) * 16 + tl] = hp[HEADS ? oc : 0][i][j];
+    // HEADS = 2: the FC weights of this thread's (at most two) tasks are requested HERE, behind the stores of the partial sums (the
+    // accumulators are dead, and not earlier: the compiler sinks the whole output stage to these stores) - they come from L2 while
+    // the partial sums go through LDS.  Task A of thread t: policy task t (part t / A, column t % A); task B: hidden task t (half
+    // t / HID, unit t % HID) for t < 2 HID, else policy task 256 + t - 2 HID.  Every load is unconditional on a clamped index (no
+    // branch per load), what lies outside the task is replaced by zero.
+    float fwa[HEADS == 2 ? FC_LP : 1], fwb[HEADS == 2 ? FC_LP : 1];
+    int qa0 = -1, qb0 = -1, fca = 0, fcb = 0, fkqa = 0, fkqb = 0;      // first contraction index (-1: no task), column, part
+    float fc_bias[HEADS == 2 ? 5 : 1];
+    if constexpr (HEADS == 2) {
+        const int A = ha.A, HID = ha.HID;
+        const int LP = (PIN + 3) >> 2, LV = (VIN + 1) >> 1;
+        const bool has_a = tid < 4 * A, is_hid = tid < 2 * HID;
+        const int t2 = 256 + tid - 2 * HID;
+        const bool has_b2 = !is_hid && t2 < 4 * A;
+        fkqa = has_a ? tid / A : 0;
+        fca = has_a ? tid - fkqa * A : 0;
+        qa0 = has_a ? fkqa * LP : -1;
+        {
+            const float* wp = ha.pfc_w + fca;
+            const int q0 = has_a ? qa0 : 0;
+#pragma unroll
+            for (int k = 0; k < FC_LP; ++k) {
+                const int q = q0 + k;
+                const float v = wp[(q < PIN ? q : PIN - 1) * A];
+                fwa[k] = (has_a && k < LP && q < PIN) ? v : 0.0f;
+            }
+        }
+        if (is_hid) {                                   // (wave-uniform when HID = 64: waves 0, 1 take the hidden layer)
+            fkqb = tid / HID;
+            fcb = tid - fkqb * HID;
+            qb0 = fkqb * LV;
+            const float* wp = ha.vfc1_w + fcb;
+#pragma unroll
+            for (int k = 0; k < FC_LP; ++k) {
+                const int q = qb0 + k;
+                const float v = wp[(q < VIN ? q : VIN - 1) * HID];
+                fwb[k] = (k < LV && q < VIN) ? v : 0.0f;
+            }
+        } else {
+            fkqb = has_b2 ? t2 / A : 0;
+            fcb = has_b2 ? t2 - fkqb * A : 0;
+            qb0 = has_b2 ? fkqb * LP : -1;
+            const float* wp = ha.pfc_w + fcb;
+            const int q0 = has_b2 ? qb0 : 0;
+#pragma unroll
+            for (int k = 0; k < FC_LP; ++k) {
+                const int q = q0 + k;
+                const float v = wp[(q < PIN ? q : PIN - 1) * A];
+                fwb[k] = (has_b2 && k < LP && q < PIN) ? v : 0.0f;
+            }
+        }
+        const int c64 = tid & 63;
+        fc_bias[0] = ha.pfc_b[c64 < A ? c64 : 0];
+        fc_bias[1] = ha.pfc_b[c64 + 64 < A ? c64 + 64 : 0];
+        fc_bias[2] = c64 < HID ? ha.vfc1_b[c64 < HID ? c64 : 0] : 0.0f;
+        fc_bias[3] = c64 < HID ? ha.vfc2_w[c64 < HID ? c64 : 0] : 0.0f;
+        fc_bias[4] = ha.vfc2_b[0];
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < OC; ++q) {
@@ -411,12 +479,74 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         const int b = t16 >> 2, tl4 = t16 & 3;
         const int row = 4 * (tl4 >> 1) + (ij >> 2), col = 4 * (tl4 & 1) + (ij & 3);
         sum += ha.hb[oc];
-        if (row < H && col < W) maps[b * (OC * HW) + oc * HW + row * W + col] = sum > 0.0f ? sum : 0.0f;
+        if (row < H && col < W) {
+            if constexpr (HEADS == 2) maps[(oc * HW + row * W + col) * 4 + b] = sum > 0.0f ? sum : 0.0f;
+            else maps[b * (OC * HW) + oc * HW + row * W + col] = sum > 0.0f ? sum : 0.0f;
+        }
     }
     __syncthreads();
-    for (int i = tid; i < NIMG2 * OC * HW; i += NTHR2) {
-        const int b = i / (OC * HW);
-        if (n0 + b < batch) ha.maps_out[(size_t)n0 * (OC * HW) + i] = maps[i];
+    if constexpr (HEADS == 1) {
+        for (int i = tid; i < NIMG2 * OC * HW; i += NTHR2) {
+            const int b = i / (OC * HW);
+            if (n0 + b < batch) ha.maps_out[(size_t)n0 * (OC * HW) + i] = maps[i];
+        }
+        return;
+    }
+    if constexpr (HEADS == 2) {
+        // ---- the FC layers: logits = maps[0 : PIN] x pfc_w + b; value = tanh(relu(maps[PIN :] x vfc1_w + b1) . vfc2_w + b2) ----
+        // `part` is dead (the barrier above): the partial sums of the tasks go there.  A map value of the four boards is ONE
+        // 16-byte LDS read (a broadcast: the threads of a task part read the same address).
+        const int A = ha.A, HID = ha.HID;
+        const f4* const mq = (const f4*)maps;
+        float* const pp = lds;                          // [part 0..3][board][FC_MAXA]
+        float* const hpart = lds + 4 * 4 * FC_MAXA;     // [half 0..1][board][64]
+        auto task = [&](int q0, const float (&w)[HEADS == 2 ? FC_LP : 1], int qmax) {
+            f4 acc4 = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int k = 0; k < (HEADS == 2 ? FC_LP : 1); ++k) {
+                const int q = q0 + k < qmax ? q0 + k : qmax;      // (past the part: weight 0 times a finite map value)
+                const f4 m = mq[q];
+                acc4[0] = __builtin_fmaf(m[0], w[k], acc4[0]);
+                acc4[1] = __builtin_fmaf(m[1], w[k], acc4[1]);
+                acc4[2] = __builtin_fmaf(m[2], w[k], acc4[2]);
+                acc4[3] = __builtin_fmaf(m[3], w[k], acc4[3]);
+            }
+            return acc4;
+        };
+        if (qa0 >= 0) {
+            const f4 r = task(qa0, fwa, PIN - 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) pp[(fkqa * 4 + b) * FC_MAXA + fca] = r[b];
+        }
+        if (tid < 2 * HID) {
+            const f4 r = task(PIN + qb0, fwb, PIN + VIN - 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) hpart[(fkqb * 4 + b) * 64 + fcb] = r[b];
+        } else if (qb0 >= 0) {
+            const f4 r = task(qb0, fwb, PIN - 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) pp[(fkqb * 4 + b) * FC_MAXA + fcb] = r[b];
+        }
+        __syncthreads();
+        const int b = wave, c64 = lane;                 // thread = (board, column): the wave of a board reduces its hidden layer
+        const bool live = n0 + b < batch;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int a = c64 + 64 * e;
+            if (a < A) {
+                const float v = ((pp[(0 * 4 + b) * FC_MAXA + a] + pp[(1 * 4 + b) * FC_MAXA + a]) + pp[(2 * 4 + b) * FC_MAXA + a]) +
+                                pp[(3 * 4 + b) * FC_MAXA + a] + fc_bias[e];
+                if (live) ha.logits[(size_t)(n0 + b) * A + a] = v;
+            }
+        }
+        float hsum = 0.0f;
+        if (c64 < HID) {
+            const float h = (hpart[(0 * 4 + b) * 64 + c64] + hpart[(1 * 4 + b) * 64 + c64]) + fc_bias[2];
+            hsum = (h > 0.0f ? h : 0.0f) * fc_bias[3];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) hsum += __shfl_xor(hsum, m, 64);
+        if (lane == 0 && live) ha.value[n0 + b] = tanhf(hsum + fc_bias[4]);
     }
 }
 
@@ -954,8 +1084,28 @@ extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* sca
 extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                       int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
                                       float* maps_out, void* stream) {
-    HeadArgs ha{ hw, hb, maps_out };
+    HeadArgs ha{};
+    ha.hw = hw; ha.hb = hb; ha.maps_out = maps_out;
     return launch_conv64<1>(x, u, scale, shift, res, nullptr, batch, H, W, 1, batch_dev, ha, stream);
+}
+
+// The last trunk convolution with the WHOLE tail behind it: both 1x1 head convolutions, the policy FC, and the value head's
+// FC -> ReLU -> FC -> tanh (grid_networks.py:44-51), written straight into logits [batch][A] / value [batch] - the forward ends
+// in this launch, neither the trunk output nor the head maps reach memory (round 4: replaces sprl_wino_conv64_heads +
+// sprl_tail_fc, one launch and 106-workgroup grid less per forward).  pfc_w: [2 H W][A] (transposed Linear weight), vfc1_w:
+// [H W][HID], vfc2_w: [HID].  Returns -1 when the shape is not covered (A > 96, HID > 64: the caller uses the two-kernel form).
+extern "C" int sprl_wino_conv64_heads_fc(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                         int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
+                                         const float* pfc_w, const float* pfc_b, const float* vfc1_w, const float* vfc1_b,
+                                         const float* vfc2_w, const float* vfc2_b, float* logits, float* value, int A, int HID,
+                                         void* stream) {
+    if (A < 1 || A > FC_MAXA || HID < 1 || HID > 64 || (2 * H * W + 3) / 4 > FC_LP || (H * W + 1) / 2 > FC_LP) return -1;
+    if (4 * A > 256 + (256 - 2 * HID)) return -1;     // every task needs a thread (two tasks per thread at most)
+    HeadArgs ha{};
+    ha.hw = hw; ha.hb = hb;
+    ha.pfc_w = pfc_w; ha.pfc_b = pfc_b; ha.vfc1_w = vfc1_w; ha.vfc1_b = vfc1_b; ha.vfc2_w = vfc2_w; ha.vfc2_b = vfc2_b;
+    ha.logits = logits; ha.value = value; ha.A = A; ha.HID = HID;
+    return launch_conv64<2>(x, u, scale, shift, res, nullptr, batch, H, W, 1, batch_dev, ha, stream);
 }
 
 // Any board size, NCHW activations [batch][64][H][W] in and out (res may be null; y must not alias x).  `u`: the weights in the
@@ -967,12 +1117,12 @@ extern "C" int sprl_wino_nchw_slack(void) { return (int)SLACK_G; }
 // output tile size of the any-board kernel for an H x W board: 3 (F(3x3,3x3), 25 positions per tile) when that needs fewer
 // position-products than 4 (F(4x4,3x3), 36 per tile) - 9x9: 9 x 25 = 225 against 9 x 36 = 324; 19x19: 4 (900 against 1225)
 extern "C" int sprl_wino_nchw_tile(int H, int W) {
-    if (getenv("SPRL_WINO_NCHW_TILE")) return atoi(getenv("SPRL_WINO_NCHW_TILE")) == 3 ? 3 : 4;
     const long long w4 = (long long)((H + 3) / 4) * ((W + 3) / 4) * 36, w3 = (long long)((H + 2) / 3) * ((W + 2) / 3) * 25;
     return w3 < w4 ? 3 : 4;
 }
+// occ: workgroups per CU the F(3x3) build is held to (0 = default: 2 on layout T, 3 on NCHW; a lab parameter, see below)
 static int launch_any_board(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y, int batch,
-                            int H, int W, int relu, int tile, int layout_t, const unsigned* batch_dev, void* stream) {
+                            int H, int W, int relu, int tile, int layout_t, int occ, const unsigned* batch_dev, void* stream) {
     if (batch <= 0) return 0;
     if (H < 1 || W < 1 || H > 64 || W > 64 || (tile != 3 && tile != 4)) return -1;
     const long long tiles = (long long)batch * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
@@ -981,9 +1131,9 @@ static int launch_any_board(const float* x, const float* u, const float* scale, 
     if ((long long)batch * board_floats * 4 >= 0x7fffff00LL) return -1;   // per-lane byte offsets: bit 31 marks "off the board"
     const dim3 grid((unsigned)((tiles + 15) / 16)), block(NTHR2);
     // F(3x3): 50 KB of LDS per workgroup, so three fit a CU if the kernel is held to 168 registers (11 of them then spill);
-    // SPRL_WINO_F3_OCC=2 selects the two-per-CU build without spills (measured: DESIGN.md section 5)
+    // occ = 2 selects the two-per-CU build without spills (measured: DESIGN.md section 5)
     // (layout T with its two-phase-deep prefetch uses the registers of the two-per-CU build)
-    const int f3_occ = getenv("SPRL_WINO_F3_OCC") ? atoi(getenv("SPRL_WINO_F3_OCC")) : (layout_t ? 2 : 3);
+    const int f3_occ = occ ? occ : (layout_t ? 2 : 3);
     // RES = 0: the first convolution of a residual block has no residual input - no loads, no adds for it
 #define SPRL_LAUNCH_NCHW(MM, OO, LL)                                                                                                      \
     do {                                                                                                                                  \
@@ -994,7 +1144,7 @@ static int launch_any_board(const float* x, const float* u, const float* scale, 
     } while (0)
     if (layout_t) {
 #if SPRL_WINO_DEEP4
-        if (tile == 4 && getenv("SPRL_WINO_F4_OCC") && atoi(getenv("SPRL_WINO_F4_OCC")) == 1) SPRL_LAUNCH_NCHW(4, 1, 1);   // lab: one workgroup per CU, 512 registers
+        if (tile == 4 && occ == 1) SPRL_LAUNCH_NCHW(4, 1, 1);   // lab: one workgroup per CU, 512 registers
         else
 #endif
         if (tile == 4) SPRL_LAUNCH_NCHW(4, 2, 1);
@@ -1010,14 +1160,24 @@ static int launch_any_board(const float* x, const float* u, const float* scale, 
 }
 extern "C" int sprl_wino_conv64_nchw_tiled(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                            float* y, int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream) {
-    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 0, batch_dev, stream);
+    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 0, 0, batch_dev, stream);
 }
 // Activations in layout T (see the kernel): x, res, y hold sprl_wino_t_board_floats(H, W, tile) floats per board; `u` from
 // sprl_wino_transform_weights_t (input channels of K step s are 4 s .. 4 s + 3).
 extern "C" int sprl_wino_t_board_floats(int H, int W, int tile) { return 64 * tile * tile * ((H + tile - 1) / tile) * ((W + tile - 1) / tile); }
 extern "C" int sprl_wino_conv64_t(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y,
                                   int batch, int H, int W, int relu, int tile, const unsigned* batch_dev, void* stream) {
-    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 1, batch_dev, stream);
+    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 1, 0, batch_dev, stream);
+}
+// lab: the same with the occupancy variant chosen by the caller (tools/nchw_lab.py); no environment switch picks it
+extern "C" int sprl_wino_conv64_t_occ(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y,
+                                      int batch, int H, int W, int relu, int tile, int occ, const unsigned* batch_dev, void* stream) {
+    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 1, occ, batch_dev, stream);
+}
+extern "C" int sprl_wino_conv64_nchw_tiled_occ(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                               float* y, int batch, int H, int W, int relu, int tile, int occ, const unsigned* batch_dev,
+                                               void* stream) {
+    return launch_any_board(x, u, scale, shift, res, y, batch, H, W, relu, tile, 0, occ, batch_dev, stream);
 }
 // F(4x4,3x3) tiling, as before
 extern "C" int sprl_wino_conv64_nchw_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,

@@ -83,6 +83,7 @@ struct TorchPlugin {
     int (*forward_on)(void*, const float*, int, int, int, int, float*, int, float*, void*, char*, int) = nullptr;
     void (*release)(void*) = nullptr;
     int (*is_native)(void*) = nullptr;
+    int (*path_info)(void*, char*, int) = nullptr;
     int (*forward_dev)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int) = nullptr;
     void (*profile_enable)(void*, int) = nullptr;
     void (*profile_read)(void*, double*, int64_t*, int64_t*) = nullptr;
@@ -125,6 +126,10 @@ struct sprl_engine {
     std::vector<void*> marks;  // k0,k1,(n0,n1) per round, resolved lazily
     std::vector<int> mark_kind;
     void* chain = nullptr;     // be::chain_new(): this engine's tree-kernel intervals on the process-wide busy clock
+    // lab switches of the engine itself, read ONCE in sprl_engine_create (never in the round loop) and reported by
+    // sprl_engine_evaluator_info: SPRL_SYNC_ROUNDS (host reads the leaf count every round), SPRL_GO_LEGAL (legal-move algorithm)
+    bool lab_sync_rounds = false;
+    std::string lab;           // the names that were set, "" = defaults
 };
 
 namespace {
@@ -176,6 +181,7 @@ int load_torch_plugin(sprl_engine* e) {
     e->torch.forward_on = (int (*)(void*, const float*, int, int, int, int, float*, int, float*, void*, char*, int))dlsym(lib, "sprl_torch_forward_on");
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
     e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
+    e->torch.path_info = (int (*)(void*, char*, int))dlsym(lib, "sprl_torch_path_info");
     e->torch.forward_dev = (int (*)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int))dlsym(
         lib, "sprl_torch_forward_dev");
     e->torch.profile_enable = (void (*)(void*, int))dlsym(lib, "sprl_torch_profile_enable");
@@ -345,8 +351,14 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     P.early_cutoff = cfg->early_cutoff;
     P.early_exp = cfg->early_exp;
     P.rest_exp = cfg->rest_exp;
-    if (const char* f = getenv("SPRL_GO_LEGAL"))           // test hook: both algorithms are checked on every board size
+    if (const char* f = getenv("SPRL_GO_LEGAL")) {         // test hook: both algorithms are checked on every board size
         P.go_legal_form = strcmp(f, "label") == 0 ? 1 : (strcmp(f, "flood") == 0 ? 2 : 0);
+        e->lab += std::string(e->lab.empty() ? "" : " ") + "SPRL_GO_LEGAL=" + f;
+    }
+    if (getenv("SPRL_SYNC_ROUNDS")) {
+        e->lab_sync_rounds = true;
+        e->lab += std::string(e->lab.empty() ? "" : " ") + "SPRL_SYNC_ROUNDS";
+    }
     P.resign_threshold = cfg->resign_threshold;
     P.resign_min_ply = cfg->resign_min_ply;
     P.use_sym = cfg->use_symmetry ? 1 : 0;
@@ -467,7 +479,7 @@ static int set_model_common(sprl_engine* e, const char* model, const void* bytes
     e->torch_model = m;
     {   // can this model run with the leaf count left on the device?  (probe with the current count, normally 0)
         char perr[256] = { 0 };
-        e->dev_batch = e->torch.forward_dev && !getenv("SPRL_SYNC_ROUNDS") &&
+        e->dev_batch = e->torch.forward_dev && !e->lab_sync_rounds &&
                        e->torch.forward_dev(m, e->P.nn_dense, &e->P.counters->leaf_total, e->P.num_slots * e->P.max_queue, e->g.planes,
                                             e->g.rows, e->g.cols, e->nn_logits, e->g.A, e->nn_value, e->stream, perr, (int)sizeof(perr)) == 0;
         be::sync();
@@ -499,7 +511,12 @@ int sprl_engine_evaluator_info(sprl_engine* e, char* buf, int32_t len) {
                        : (e->torch.is_native && e->torch_model && e->torch.is_native(e->torch_model))
                            ? "LibTorch-ROCm: MIOpen convolutions + fused bias/BN/ReLU epilogue kernel"
                            : "LibTorch-ROCm: TorchScript graph (bias hoisted for the JIT fuser)";
-    snprintf(buf, (size_t)len, "%s", what);
+    // the resolved path of the plugin (kind, fused tail, lab switches set when the model was loaded) and the engine's own lab switches:
+    // a timed run checks "lab=[]" in both (bench.py)
+    char path[384] = { 0 };
+    if (e->eval_kind == SPRL_EVAL_NETWORK && !e->forward_cb && e->torch_model && e->torch.path_info)
+        e->torch.path_info(e->torch_model, path, (int)sizeof(path));
+    snprintf(buf, (size_t)len, "%s%s%s%s; engine lab=[%s]", what, path[0] ? " {" : "", path, path[0] ? "}" : "", e->lab.c_str());
     return 0;
 }
 

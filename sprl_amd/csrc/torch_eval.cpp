@@ -55,10 +55,21 @@ extern "C" int sprl_stem_conv3x3_nchw(const float* planes, const float* w, const
 extern "C" int sprl_wino_conv64_heads(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                       int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
                                       float* maps_out, void* stream);
-extern "C" int sprl_tail_fc(const float* x, const float* maps_in, const float* hw, const float* hb, const float* pfc_w,
-                            const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
-                            float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
-                            const unsigned* batch_dev, void* stream);
+extern "C" int sprl_tail_fc_form(const float* x, const float* maps_in, const float* hw, const float* hb, const float* pfc_w,
+                                 const float* pfc_b, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                                 float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID, int no_mfma,
+                                 const unsigned* batch_dev, void* stream);
+extern "C" int sprl_wino_conv64_heads_fc(const float* x, const float* u, const float* scale, const float* shift, const float* res,
+                                         int batch, int H, int W, const unsigned* batch_dev, const float* hw, const float* hb,
+                                         const float* pfc_w, const float* pfc_b, const float* vfc1_w, const float* vfc1_b,
+                                         const float* vfc2_w, const float* vfc2_b, float* logits, float* value, int A, int HID,
+                                         void* stream);
+extern "C" int sprl_wino_conv64_t_occ(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y,
+                                      int batch, int H, int W, int relu, int tile, int occ, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_stem_conv3x3_w_form(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                        int batch, int P, int H, int W, int valu, const unsigned* batch_dev, void* stream);
+extern "C" int sprl_stem_conv3x3_nchw_valu(const float* planes, const float* w, const float* scale, const float* shift, float* y,
+                                           long long batch, int P, int H, int W, void* stream);
 extern "C" int sprl_tail_heads_fc(const float* x, const float* hw, const float* hb, const float* pfc_w, const float* pfc_b,
                                   const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
                                   float* logits, float* value, int batch, int H, int W, int PC, int VC, int A, int HID,
@@ -67,6 +78,46 @@ extern "C" int sprl_heads_conv1x1_relu(const float* x, const float* w, const flo
                                        int64_t batch, int C, int HW, int PC, int VC, int board_w, void* stream);
 
 namespace {
+// Lab switches: environment toggles that move a forward off the hand-written path or pick a variant of it (A/B measurements,
+// tests of the fallback paths).  They are read ONCE, when a model is loaded - never per forward or per launch - kept in the model
+// and reported by sprl_torch_path_info, so a timed run can refuse to start on anything but the default path (bench.py does).
+struct PathSwitches {
+    bool no_native = false, no_rewrite = false, no_winograd = false, no_conv_tail = false, no_conv_fc = false, no_nchw_native = false,
+         no_nchw_stem = false, no_winograd_nchw = false, no_fused_tail = false, stem_valu = false, tail_no_mfma = false;
+    int nchw_tile = 0, f3_occ = 0;
+    std::string active;                  // the names that were set, space separated ("" = the default path)
+    static PathSwitches from_env() {
+        PathSwitches sw;
+        auto flag = [&](const char* name, bool& dst) {
+            if (getenv(name)) {
+                dst = true;
+                sw.active += std::string(sw.active.empty() ? "" : " ") + name;
+            }
+        };
+        auto num = [&](const char* name, int& dst) {
+            if (const char* v = getenv(name)) {
+                dst = atoi(v);
+                sw.active += std::string(sw.active.empty() ? "" : " ") + name + "=" + v;
+            }
+        };
+        flag("SPRL_TORCH_NO_NATIVE", sw.no_native);
+        flag("SPRL_TORCH_NO_REWRITE", sw.no_rewrite);
+        flag("SPRL_TORCH_NO_WINOGRAD", sw.no_winograd);
+        flag("SPRL_TORCH_NO_CONV_TAIL", sw.no_conv_tail);
+        flag("SPRL_TORCH_NO_CONV_FC", sw.no_conv_fc);
+        flag("SPRL_TORCH_NO_NCHW_NATIVE", sw.no_nchw_native);
+        flag("SPRL_TORCH_NO_NCHW_STEM", sw.no_nchw_stem);
+        flag("SPRL_TORCH_NO_WINOGRAD_NCHW", sw.no_winograd_nchw);
+        flag("SPRL_TORCH_NO_FUSED_TAIL", sw.no_fused_tail);
+        flag("SPRL_STEM_VALU", sw.stem_valu);
+        flag("SPRL_TAIL_NO_MFMA", sw.tail_no_mfma);
+        num("SPRL_WINO_NCHW_TILE", sw.nchw_tile);
+        num("SPRL_WINO_F3_OCC", sw.f3_occ);
+        if (sw.nchw_tile != 0 && sw.nchw_tile != 3) sw.nchw_tile = 4;
+        return sw;
+    }
+};
+
 // The network of src/networks/grid_networks.py:30-79 with its parameters taken from the traced module, evaluated as
 // MIOpen convolutions (no bias) + one hand-written fused epilogue pass per convolution (cnn_epilogue.hip).
 struct NativeNet {
@@ -148,11 +199,13 @@ struct ConvProfile {
 struct Model {
     torch::jit::Module module;
     int device = 0;
+    PathSwitches sw;             // resolved once at load
     NativeNet native;
     ConvProfile prof;
     at::Tensor act[3], maps;     // activation buffers of the hand-written path, kept across calls (no allocator traffic, any stream)
     at::Tensor nact[3], npmaps;  // the same for boards wider than 8 (NCHW with the slack sprl_wino_conv64_nchw needs; policy head maps)
-    int64_t nact_boards = 0, nact_hw = 0;
+    int64_t nact_floats = 0, nact_pmaps = 0;     // allocated sizes: activations (floats per buffer), policy maps (floats)
+    int last_tail = 0;           // what the last 8x8 forward ended in: 2 = conv + heads + FC in one launch, 1 = heads fused + FC kernel, 0 = separate tail
 };
 
 // scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta  (BatchNorm2d eval, eps = 1e-5)
@@ -254,7 +307,7 @@ void build_native(Model* m) {
     // every tensor of the traced module must be accounted for, otherwise this is not the architecture we know
     size_t expected = 6 + n.blocks.size() * 12 + 10 + (1 + 2 * n.blocks.size());   // + num_batches_tracked buffers
     if (t.size() != expected) return;
-    n.wino = !n.blocks.empty() && n.stem_w.size(0) == 64 && !getenv("SPRL_TORCH_NO_WINOGRAD");
+    n.wino = !n.blocks.empty() && n.stem_w.size(0) == 64 && !m->sw.no_winograd;
     for (const auto& b : n.blocks)
         n.wino = n.wino && b.w1.size(0) == 64 && b.w1.size(1) == 64 && b.w2.size(0) == 64 && b.w2.size(1) == 64;
     if (n.wino)
@@ -285,8 +338,8 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
         (void)hipDeviceSynchronize();            // the buffers may be used on another stream than the one that allocated them
     }
     at::Tensor x = mdl->act[0], y = mdl->act[1], z = mdl->act[2];
-    if (sprl_stem_conv3x3_w(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
-                            n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, batch_dev, stream) != 0)
+    if (sprl_stem_conv3x3_w_form(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
+                                 n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, mdl->sw.stem_valu ? 1 : 0, batch_dev, stream) != 0)
         return false;
     if (prof) prof->open((hipStream_t)stream);       // one event pair around all the trunk convolutions of this forward
     auto conv = [&](const at::Tensor& src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res,
@@ -299,11 +352,30 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
     const int A0 = (int)n.pfc_w.size(1), HID0 = (int)n.vfc1_w.size(1);
     // the last convolution can carry the whole tail (heads + FC layers) behind its inverse transform
     const bool fuse_last = logits_out && value_out && n.pc == 2 && n.vc == 1 && HID0 <= 64 && n.vfc2_w.numel() == HID0 &&
-                           !getenv("SPRL_TORCH_NO_CONV_TAIL");
+                           !mdl->sw.no_conv_tail;
     for (size_t bi = 0; bi < n.blocks.size(); ++bi) {
         const auto& b = n.blocks[bi];
         if (!conv(x, b.u1, b.s1, b.t1, nullptr, y)) return false;
         if (fuse_last && bi + 1 == n.blocks.size()) {
+            // last convolution + both head convolutions + the FC layers in ONE kernel: the forward ends in this launch (round 4)
+            if (!mdl->sw.no_conv_fc) {
+                const int rc = sprl_wino_conv64_heads_fc(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(),
+                                                         b.t2.data_ptr<float>(), x.data_ptr<float>(), B, H, W, batch_dev,
+                                                         n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), n.pfc_w.data_ptr<float>(),
+                                                         n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
+                                                         n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, A0, HID0,
+                                                         stream);
+                if (rc == 0) {
+                    if (prof) {
+                        prof->note(B);
+                        prof->close((hipStream_t)stream);
+                    }
+                    mdl->last_tail = 2;
+                    *wrote_outputs = true;
+                    return true;
+                }
+                if (rc != -1) return false;      // (-1: shape not covered - the two-kernel form below)
+            }
             // last convolution + both head convolutions in one kernel (the trunk output is never written), then the FC layers
             at::Tensor maps = mdl->maps;
             const int rc = sprl_wino_conv64_heads(y.data_ptr<float>(), b.u2.data_ptr<float>(), b.s2.data_ptr<float>(),
@@ -315,11 +387,12 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                 prof->close((hipStream_t)stream);
             }
             if (rc != 0) return false;
-            if (sprl_tail_fc(nullptr, maps.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
-                             n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
-                             n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A0, HID0,
-                             batch_dev, stream) != 0)
+            if (sprl_tail_fc_form(nullptr, maps.data_ptr<float>(), n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(),
+                                  n.pfc_w.data_ptr<float>(), n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
+                                  n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A0, HID0,
+                                  mdl->sw.tail_no_mfma ? 1 : 0, batch_dev, stream) != 0)
                 return false;
+            mdl->last_tail = 1;
             *wrote_outputs = true;
             return true;
         }
@@ -334,6 +407,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                            n.pfc_b.data_ptr<float>(), n.vfc1_w.data_ptr<float>(), n.vfc1_b.data_ptr<float>(),
                            n.vfc2_w.data_ptr<float>(), n.vfc2_b.data_ptr<float>(), logits_out, value_out, B, H, W, n.pc, n.vc, A,
                            HID, batch_dev, stream) == 0) {
+        mdl->last_tail = 0;
         *wrote_outputs = true;                   // heads + FC layers fused, results already in the caller's buffers
         return true;
     }
@@ -358,18 +432,18 @@ at::Tensor nchw_act(int64_t B, int H, int W, const at::TensorOptions& opts) {
 // written in place.  No library call, no allocation, no copy, no synchronisation per forward (the earlier
 // wide-board path needed the batch size on the host for three rocBLAS GEMMs and allocated / copied per round).
 // Returns false when this network / board is not covered (the caller falls back to the library path).
-bool nchw_covered(const NativeNet& n, int P, int H, int W, int actions) {
+bool nchw_covered(const Model* mdl, int P, int H, int W, int actions) {
+    const NativeNet& n = mdl->native;
     const int HID = (int)n.vfc1_w.size(1);
     return n.wino && (P == 3 || P == 17) && H >= 1 && W >= 1 && H <= 64 && W <= 64 && n.pc == 2 && n.vc == 1 &&
            n.pfc_w.size(0) == (int64_t)2 * H * W && n.pfc_w.size(1) == actions && n.vfc1_w.size(0) == (int64_t)H * W && HID <= 64 &&
            n.vfc2_w.numel() == HID && (size_t)(3 * 64 + 3 + (3 * H * W > 512 ? 8 : 16) * (3 * H * W + 5 * 64)) * 4 <= 64 * 1024 &&
-           (size_t)((3 * H * W > 512 ? 8 : 16) * (2 * H * W + 128)) * 4 <= 64 * 1024 &&
-           !getenv("SPRL_TORCH_NO_NCHW_NATIVE");
+           (size_t)((3 * H * W > 512 ? 8 : 16) * (2 * H * W + 128)) * 4 <= 64 * 1024 && !mdl->sw.no_nchw_native;
 }
 
 bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W, ConvProfile* prof, float* logits_out,
                   float* value_out, const unsigned* batch_dev, void* stream, const at::TensorOptions& opts) {
-    const int tile = sprl_wino_nchw_tile(H, W);
+    const int tile = mdl->sw.nchw_tile ? mdl->sw.nchw_tile : sprl_wino_nchw_tile(H, W);
     if (mdl->native.ut_tile != tile) {               // first board of this tiling on this model: filters for the layout-T kernel
         for (auto& b : mdl->native.blocks) {
             b.u1t = wino_weights(b.w1, tile, true);
@@ -382,11 +456,13 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
     const int64_t board_floats = sprl_wino_t_board_floats(H, W, tile);
     const int A = (int)n.pfc_w.size(1), HID = (int)n.vfc1_w.size(1);
     if ((long long)cap * board_floats * 4 >= 0x7fffff00LL || (long long)cap * H * W * P * 4 >= 0x40000000LL) return false;
-    if (!mdl->nact[0].defined() || mdl->nact_boards < cap || mdl->nact_hw != (int64_t)H * W) {
+    // the cached buffers are keyed on what they HOLD (floats), not on (boards, H * W): 4x16 and 8x8, or another tiling of the same
+    // board, have other padded sizes
+    if (!mdl->nact[0].defined() || mdl->nact_floats < (int64_t)cap * board_floats || mdl->nact_pmaps < (int64_t)cap * 2 * H * W) {
         for (auto& t : mdl->nact) t = at::empty({ (int64_t)cap * board_floats }, opts);      // layout T (cnn_wino.hip)
-        mdl->npmaps = at::empty({ (int64_t)cap, (int64_t)2 * H * W }, opts);
-        mdl->nact_boards = cap;
-        mdl->nact_hw = (int64_t)H * W;
+        mdl->npmaps = at::empty({ (int64_t)cap * 2 * H * W }, opts);
+        mdl->nact_floats = (int64_t)cap * board_floats;
+        mdl->nact_pmaps = (int64_t)cap * 2 * H * W;
         (void)hipDeviceSynchronize();            // the buffers may be used on another stream than the one that allocated them
     }
     float *x = mdl->nact[0].data_ptr<float>(), *ya = mdl->nact[1].data_ptr<float>(), *za = mdl->nact[2].data_ptr<float>();
@@ -395,8 +471,8 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
         return false;
     if (prof) prof->open((hipStream_t)stream);       // one event pair around all the trunk convolutions of this forward
     auto conv = [&](const float* src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res, float* dst) {
-        const int rc = sprl_wino_conv64_t(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1, tile,
-                                          batch_dev, stream);
+        const int rc = sprl_wino_conv64_t_occ(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1, tile,
+                                              mdl->sw.f3_occ, batch_dev, stream);
         if (prof) prof->note(cap);
         return rc == 0;
     };
@@ -419,17 +495,18 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
     if (wino) {
         if (!forward_wino(mdl, in, p, v, prof, logits_out, value_out, wrote_outputs, nullptr, stream)) return false;
         if (*wrote_outputs) return true;
-    } else if (logits_out && value_out && in.is_contiguous() && nchw_covered(n, P0, H0, W0, (int)n.pfc_w.size(1)) &&
+    } else if (logits_out && value_out && in.is_contiguous() && nchw_covered(mdl, P0, H0, W0, (int)n.pfc_w.size(1)) &&
                forward_nchw(mdl, in.data_ptr<float>(), (int)in.size(0), P0, H0, W0, prof, logits_out, value_out, nullptr, stream, in.options())) {
         *wrote_outputs = true;                   // the whole forward in our kernels, results already in the caller's buffers
         return true;
     } else {
         at::Tensor x;
-        if ((P0 == 3 || P0 == 17) && n.stem_w.size(0) == 64 && in.is_contiguous() && !getenv("SPRL_TORCH_NO_NCHW_STEM")) {
+        if ((P0 == 3 || P0 == 17) && n.stem_w.size(0) == 64 && in.is_contiguous() && !mdl->sw.no_nchw_stem) {
             // hand-written stem for any board size (Go 9x9 / 19x19): conv + folded BN + ReLU in one kernel
             x = nchw_act(in.size(0), H0, W0, in.options());
-            if (sprl_stem_conv3x3_nchw(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
-                                       n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), in.size(0), P0, H0, W0, stream) != 0)
+            if ((mdl->sw.stem_valu ? sprl_stem_conv3x3_nchw_valu : sprl_stem_conv3x3_nchw)(
+                    in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(), n.stem_shift.data_ptr<float>(),
+                    x.data_ptr<float>(), in.size(0), P0, H0, W0, stream) != 0)
                 return false;
         } else {
             x = at::conv2d(in, n.stem_w, {}, 1, 1);
@@ -437,7 +514,7 @@ bool forward_native(Model* mdl, const at::Tensor& in, at::Tensor& logits, at::Te
         }
         // boards wider than 8: the trunk still runs on the hand-written Winograd/MFMA kernel (any-board variant, NCHW);
         // the stem (P planes) and the heads keep the library convolution / the NCHW heads kernel
-        const bool trunk_wino = n.wino && H0 <= 64 && W0 <= 64 && !getenv("SPRL_TORCH_NO_WINOGRAD_NCHW");
+        const bool trunk_wino = n.wino && H0 <= 64 && W0 <= 64 && !mdl->sw.no_winograd_nchw;
         at::Tensor ya, za;
         if (trunk_wino) {
             if (x.storage_offset() < 4 || x.storage().nbytes() < (size_t)(x.storage_offset() + x.numel()) * 4 + 32) {   // (library stem: no slack yet)
@@ -560,8 +637,9 @@ static void* load_common(const char* path, const void* bytes, long long nbytes, 
             m->module = torch::jit::load(in, where);
         }
         m->module.eval();                       // GridNetwork.hpp:67
-        if (device >= 0 && !getenv("SPRL_TORCH_NO_NATIVE")) build_native(m);
-        if (!getenv("SPRL_TORCH_NO_REWRITE")) {
+        m->sw = PathSwitches::from_env();       // the only place the environment is read
+        if (device >= 0 && !m->sw.no_native) build_native(m);
+        if (!m->sw.no_rewrite) {
             try {
                 torch::jit::Module frozen = torch::jit::freeze_module(m->module);
                 hoist_conv_bias(frozen);
@@ -607,7 +685,7 @@ static int forward_common(void* handle, const float* planes, int batch, int npla
         auto in = torch::from_blob(const_cast<float*>(planes), { batch, nplanes, rows, cols }, opts);
         at::Tensor lo, va;
         bool wrote = false;
-        const bool fuse_tail = m->device >= 0 && m->native.ok && m->native.pfc_w.size(1) == actions && !getenv("SPRL_TORCH_NO_FUSED_TAIL");
+        const bool fuse_tail = m->device >= 0 && m->native.ok && m->native.pfc_w.size(1) == actions && !m->sw.no_fused_tail;
         if (m->native.ok && forward_native(m, in, lo, va, &m->prof, fuse_tail ? logits : nullptr,
                                            fuse_tail ? value : nullptr, &wrote, stream) && wrote)
             return 0;
@@ -662,12 +740,12 @@ int sprl_torch_forward_dev(void* handle, const float* planes, const unsigned* ba
     try {
         auto* m = static_cast<Model*>(handle);
         const NativeNet& n = m->native;
-        if (!(n.ok && n.wino) || m->device < 0 || n.pfc_w.size(1) != actions || getenv("SPRL_TORCH_NO_FUSED_TAIL")) return -2;
+        if (!(n.ok && n.wino) || m->device < 0 || n.pfc_w.size(1) != actions || m->sw.no_fused_tail) return -2;
         c10::InferenceMode guard;
         auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, (c10::DeviceIndex)m->device);
         if (!((nplanes == 3 || nplanes == 17) && ((rows == 8 && cols == 8) || (rows == 6 && cols == 7) || (rows == 7 && cols == 7)))) {
             // boards wider than 8: the NCHW kernels, same contract
-            if (!nchw_covered(n, nplanes, rows, cols, actions)) return -2;
+            if (!nchw_covered(m, nplanes, rows, cols, actions)) return -2;
             return forward_nchw(m, planes, max_batch, nplanes, rows, cols, &m->prof, logits, value, batch_dev, stream, opts) ? 0 : -2;
         }
         auto in = torch::from_blob(const_cast<float*>(planes), { max_batch, nplanes, rows, cols }, opts);
@@ -682,6 +760,16 @@ int sprl_torch_forward_dev(void* handle, const float* planes, const unsigned* ba
 }
 
 void sprl_torch_free(void* handle) { delete static_cast<Model*>(handle); }
+
+// What the model's forward resolves to: "kind=<0|1|2> tail=<2|1|0> lab=[<switches that were set when it was loaded>]".  kind as
+// sprl_torch_is_native; tail (boards up to 8x8, after the first forward): 2 = last convolution + heads + FC layers in one launch,
+// 1 = heads fused into the last convolution + FC kernel, 0 = separate tail kernel.  An empty lab list = the default path.
+int sprl_torch_path_info(void* handle, char* buf, int len) {
+    if (!handle || !buf || len < 1) return -1;
+    const Model* m = static_cast<Model*>(handle);
+    snprintf(buf, (size_t)len, "kind=%d tail=%d lab=[%s]", m->native.ok ? (m->native.wino ? 2 : 1) : 0, m->last_tail, m->sw.active.c_str());
+    return 0;
+}
 
 // 2: recognised architecture with a 64-channel trunk — stem, Winograd/MFMA trunk and heads all in the hand-written kernels;
 // 1: recognised, convolutions in MIOpen + the hand-written fused epilogue; 0: generic (rewritten) TorchScript graph

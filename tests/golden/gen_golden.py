@@ -357,12 +357,80 @@ def g_go19():
     save("g_go19.npz", **out)
 
 
+def g9c_go_networks():
+    """The Go-shape networks of BASELINE configs 4 / 5 (scripts/go_controller.py:44-45: MODEL_NUM_BLOCKS = 6, 64 channels, history 8
+    -> 17 input planes): BasicGridNetwork(9, 9, 82, 8, 6, 64) and (19, 19, 362, 8, 6, 64) evaluated by the REFERENCE's own module
+    on CPU in fp32 and in float64, netfill weights at gains 1 and 2, Go-like inputs.  Stored: seeds, outputs (inputs and weights
+    are reproducible from the seeds alone, netfill.py)."""
+    import torch
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    from src.networks.grid_networks import BasicGridNetwork  # reference definition, this container only
+    sys.path.insert(0, OUT)
+    import netfill
+    torch.set_num_threads(8)
+    seed = 20261005
+    out = dict(seed=np.array([seed], np.int64), gains=np.array([1.0, 2.0]), history=np.array([8], np.int64),
+               blocks=np.array([6], np.int64), channels=np.array([64], np.int64))
+    for width, actions, n in ((9, 82, 16), (19, 362, 8)):
+        x = netfill.go_like_inputs(n, width, 8, seed + width)
+        out[f"n{width}"] = np.array([n], np.int64)
+        for gi, gain in enumerate((1.0, 2.0)):
+            ref_net = netfill.fill_state_dict(BasicGridNetwork(width, width, actions, 8, 6, 64), seed + 100 * width + gi, gain).eval()
+            with torch.no_grad():
+                logits, value = ref_net(torch.from_numpy(x))
+                ld, vd = ref_net.double()(torch.from_numpy(x).double())
+            out[f"logits{width}_{gi}"], out[f"value{width}_{gi}"] = logits.numpy(), value.numpy()
+            out[f"logits{width}_f64_{gi}"], out[f"value{width}_f64_{gi}"] = ld.numpy(), vd.numpy()
+            print(f"  {width}x{width} gain {gain}: |logits| <= {np.abs(logits.numpy()).max():.3f}, fp32 vs f64 {np.abs(logits.numpy() - ld.numpy()).max():.2e}")
+    save("g9c_go_networks.npz", **out)
+
+
+def _cnn_dist_worker(args):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    return parity.reference_cnn_games(args)
+
+
+def g_cnn_dist(games=1024, procs=8):
+    """Per-game statistics of `games` Othello games of the REFERENCE's selfPlay + GridNetwork (LibTorch-CPU, oracle/_ref) with a
+    traced 2 x 64 network whose weights come from netfill (seed, gain 2: logits of a few units, so the policy head matters):
+    200 traversals/move, batch 8 / queue 4, D4, Dirichlet(0.25, 0.3).  Columns: plies, outcome of Player ZERO, network
+    evaluations, mean entropy of the root-visit pdfs.  The GPU test plays as many games with the same model and compares."""
+    import multiprocessing as mp
+    import time
+    sys.path.insert(0, OUT)
+    import netfill
+    from sprl_amd.network import GridResNet, trace_to_file
+    seed, gain, trav, rng_seed = 20261006, 2.0, 200, 777
+    net = netfill.fill_state_dict(GridResNet(8, 8, 65, 1, 2, 64), seed, gain).eval()
+    with tempfile.TemporaryDirectory() as td:
+        path = trace_to_file(net, os.path.join(td, "dist.pt"), "othello")
+        per = games // procs
+        t0 = time.time()
+        with mp.get_context("spawn").Pool(procs) as pool:
+            parts = pool.map(_cnn_dist_worker, [(path, per, trav, rng_seed, 100000 + per * i) for i in range(procs)])
+    rows = np.array([r for part in parts for r in part], np.float64)
+    print(f"  {len(rows)} reference games in {time.time() - t0:.0f} s: plies {rows[:, 0].mean():.2f} +- {rows[:, 0].std():.2f}, outcome "
+          f"{rows[:, 1].mean():+.3f}, evals {rows[:, 2].mean():.1f} +- {rows[:, 2].std():.1f}, entropy {rows[:, 3].mean():.4f} +- {rows[:, 3].std():.4f}")
+    save("g_cnn_dist.npz", stats=rows, net_seed=np.array([seed], np.int64), gain=np.array([gain]), traversals=np.array([trav], np.int64),
+         rng_seed=np.array([rng_seed], np.int64), first_stream=np.array([100000], np.int64))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trainer":
         g_trainer()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g9b":
         g9b_baseline_network()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g9c":
+        g9c_go_networks()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g_cnn_dist":
+        assert pyref.available(True), "run `make -C oracle ref_torch` first"
+        g_cnn_dist()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "go9":          # only the 9x9 fixtures (needs `make -C oracle ref_go9`)
         assert pyref.available(variant="go9"), "run `make -C oracle ref_go9` first"
@@ -380,6 +448,8 @@ if __name__ == "__main__":
     g5_games()
     g7_g9_network()
     g9b_baseline_network()
+    g9c_go_networks()
+    g_cnn_dist()
     g_trainer()
     g10_matches()
     if pyref.available(variant="go9"):

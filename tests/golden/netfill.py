@@ -46,3 +46,28 @@ def othello_like_inputs(n, seed):
         x[i, 1] = (r >= fill / 2) & (r < fill)
         x[i, 2] = float(rs.randint(2))
     return x
+
+
+def go_like_inputs(n, width, history, seed):
+    """n Go input stacks [2 * history + 1][width][width] in the reference's plane order (own / opponent stones of the last
+    `history` positions, then the colour plane): a random game-like sequence - stones are added one per position, older
+    positions are prefixes of newer ones, a few stones disappear (captures)."""
+    rs = np.random.RandomState(seed)
+    P = 2 * history + 1
+    x = np.zeros((n, P, width, width), np.float32)
+    for i in range(n):
+        cells = rs.permutation(width * width)
+        nstones = int(rs.uniform(0.1, 0.7) * width * width) + history
+        colour = rs.randint(2, size=width * width)
+        for h in range(history):                   # position h plies ago holds the first nstones - h stones
+            own = np.zeros(width * width, np.float32)
+            opp = np.zeros(width * width, np.float32)
+            live = cells[:max(0, nstones - h)]
+            live = live[rs.uniform(size=len(live)) > 0.03]         # a few captured
+            side = colour[live] ^ (h & 1)
+            own[live[side == 0]] = 1.0
+            opp[live[side == 1]] = 1.0
+            x[i, 2 * h] = own.reshape(width, width)
+            x[i, 2 * h + 1] = opp.reshape(width, width)
+        x[i, P - 1] = float(rs.randint(2))
+    return x

@@ -235,10 +235,11 @@ def test_stem_any_board_layout_t(plug, P, H, W, B, tile):
 
 @pytest.mark.parametrize("P,H,W,B", [(17, 9, 9, 7), (17, 19, 19, 3), (3, 13, 6, 11), (17, 9, 9, 513), (3, 9, 9, 1)])
 def test_stem_any_board_mfma_and_valu_forms(plug, P, H, W, B):
-    """Stem for boards wider than 8 (cnn_epilogue.hip: stem_mfma_nchw_kernel on the matrix cores, and the VALU form behind
-    SPRL_STEM_VALU) against conv2d in float64: conv3x3 P -> 64, folded scale/shift, ReLU, NCHW in and out."""
+    """Stem for boards wider than 8 (cnn_epilogue.hip: stem_mfma_nchw_kernel on the matrix cores, and the VALU form,
+    sprl_stem_conv3x3_nchw_valu) against conv2d in float64: conv3x3 P -> 64, folded scale/shift, ReLU, NCHW in and out."""
     import torch
     plug.sprl_stem_conv3x3_nchw.argtypes = [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    plug.sprl_stem_conv3x3_nchw_valu.argtypes = plug.sprl_stem_conv3x3_nchw.argtypes
     torch.manual_seed(P * 100 + H + B)
     x = (torch.rand(B, P, H, W, device="cuda") < 0.4).float() + 0.25 * torch.randn(B, P, H, W, device="cuda")
     w = torch.randn(64, P, 3, 3, device="cuda") * 0.2
@@ -247,14 +248,10 @@ def test_stem_any_board_mfma_and_valu_forms(plug, P, H, W, B):
     want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1)
                       + shift.double().view(1, -1, 1, 1))
     for valu in (False, True):
-        if valu:
-            os.environ["SPRL_STEM_VALU"] = "1"
-        try:
-            y = torch.full((B, 64, H, W), float("nan"), device="cuda")
-            rc = plug.sprl_stem_conv3x3_nchw(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, P, H, W, None)
-            assert rc == 0
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop("SPRL_STEM_VALU", None)
+        fn = plug.sprl_stem_conv3x3_nchw_valu if valu else plug.sprl_stem_conv3x3_nchw      # (an entry point, not an environment switch)
+        y = torch.full((B, 64, H, W), float("nan"), device="cuda")
+        rc = fn(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, P, H, W, None)
+        assert rc == 0
+        torch.cuda.synchronize()
         err = (y.double() - want).abs().max().item()
         assert err < 1e-5, (P, H, W, B, valu, err)

@@ -248,6 +248,7 @@ def test_handwritten_cnn_against_reference_golden_baseline_shape(lib, golden, tm
         h = plug.sprl_torch_load(path.encode(), 0, err, 512)
         assert h and plug.sprl_torch_is_native(h) == 2, err.value
         lo, va = _plugin_forward(plug, h, x, 65)
+        assert _path_info(plug, h) == "kind=2 tail=2 lab=[]"         # the forward ended in the last convolution's launch, no lab switch
         plug.sprl_torch_free(h)
         e_ref = max(np.abs(lo - g[f"logits{gi}"]).max(), np.abs(va - g[f"value{gi}"].reshape(-1)).max())
         e_f64 = max(np.abs(lo - g[f"logits_f64_{gi}"]).max(), np.abs(va - g[f"value_f64_{gi}"].reshape(-1)).max())
@@ -261,13 +262,27 @@ def test_handwritten_cnn_against_reference_golden_baseline_shape(lib, golden, tm
     open(os.path.join(ROOT, "gpurun_out", "cnn_error.txt"), "w").write("\n".join(report) + "\n")
 
 
-@pytest.mark.parametrize("game", ["othello", "connect_four", "go7"])
-def test_native_cnn_path_matches_torchscript(lib, game, tmp_path):
+def _path_info(plug, h):
+    import ctypes as C
+    plug.sprl_torch_path_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(384)
+    assert plug.sprl_torch_path_info(h, buf, 384) == 0
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("game,tail", [("othello", 2), ("connect_four", 2), ("go7", 2), ("othello", 1), ("go7", 1)])
+def test_native_cnn_path_matches_torchscript(lib, game, tail, tmp_path, monkeypatch):
     """The plugin's recognised-architecture path — stem kernel, Winograd F(4x4,3x3) trunk on fp32 MFMA with fused
-    BN/residual/ReLU, fused 1x1 heads (cnn_wino.hip, cnn_epilogue.hip) — against the plain TorchScript fp32 forward of the
-    same file: 1e-5 absolute on logits and value (CNN_ATOL below; measured errors in profiles/r02_cnn_error.txt)."""
+    BN/residual/ReLU, the 1x1 heads and (round 4) the FC layers fused behind the last convolution (cnn_wino.hip,
+    cnn_epilogue.hip) — against the plain TorchScript fp32 forward of the same file: 1e-5 absolute on logits and value
+    (CNN_ATOL below; measured errors in profiles/r02_cnn_error.txt).  tail = 2: the forward ends in the last convolution's
+    launch (the default); tail = 1: the two-kernel form (heads fused, FC kernel), kept for shapes the fused form does not
+    cover and selected here by the lab switch SPRL_TORCH_NO_CONV_FC - which is read when the model is LOADED and must show
+    up in sprl_torch_path_info."""
     import ctypes as C
     import torch
+    if tail == 1:
+        monkeypatch.setenv("SPRL_TORCH_NO_CONV_FC", "1")
     from sprl_amd.network import GAME_SHAPES, make_network, trace_to_file
     model = trace_to_file(make_network(game, 2, 64, seed=1), str(tmp_path / f"traced_{game}.pt"), game)
     rows, cols, actions, hist = GAME_SHAPES[game]
@@ -293,6 +308,12 @@ def test_native_cnn_path_matches_torchscript(lib, game, tmp_path):
             rl, rv = ref(x)
         np.testing.assert_allclose(lo.cpu().numpy(), rl.cpu().numpy(), atol=CNN_ATOL, rtol=0)
         np.testing.assert_allclose(va.cpu().numpy(), rv.cpu().numpy().reshape(-1), atol=CNN_ATOL, rtol=0)
+    assert _path_info(plug, h) == f"kind=2 tail={tail} lab=[{'SPRL_TORCH_NO_CONV_FC' if tail == 1 else ''}]"
+    monkeypatch.delenv("SPRL_TORCH_NO_CONV_FC", raising=False)
+    h2 = plug.sprl_torch_load(model.encode(), 0, err, 512)           # the switch was read at load: a model loaded now has none
+    assert _path_info(plug, h2).endswith("lab=[]")
+    plug.sprl_torch_free(h2)
+    plug.sprl_torch_free(h)
 
 
 def test_full_size_properties(lib):
