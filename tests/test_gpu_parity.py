@@ -293,6 +293,7 @@ def test_native_cnn_path_matches_torchscript(lib, game, tail, tmp_path, monkeypa
     plug.sprl_torch_forward.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p,
                                                                                  C.c_char_p, C.c_int]
     plug.sprl_torch_is_native.argtypes = [C.c_void_p]
+    plug.sprl_torch_free.argtypes = [C.c_void_p]
     err = C.create_string_buffer(512)
     h = plug.sprl_torch_load(model.encode(), 0, err, 512)
     assert h, err.value
