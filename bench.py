@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--resign-threshold", type=float, default=-1.0,
                     help="extension (BASELINE config 5), 0 = off as in the reference (default: off, go19: 0.05)")
     ap.add_argument("--resign-min-ply", type=int, default=-1, help="default 0 (go19: 60)")
+    ap.add_argument("--allow-lab", action="store_true",
+                    help="A/B measurements only: accept SPRL_* lab switches (the JSON line then names them in config.evaluator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
@@ -349,6 +351,14 @@ def main():
         d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
         verified = verify_last_shards()
         info = engines[0].evaluator_info() if model_path else args.model
+        if model_path and not args.allow_lab:
+            # the number is only valid on the default hand-written path: the evaluator string carries the plugin's resolved path and
+            # every lab switch (SPRL_*) that was set when the model was loaded / the engine created
+            for en in engines:
+                ei = en.evaluator_info()
+                if "hand-written gfx950 CNN" not in ei or ei.count("lab=[]") != 2:
+                    raise SystemExit(f"bench.py: refusing to report a timed run on a non-default evaluator path: {ei!r} "
+                                     "(unset the SPRL_* lab switches, or pass --allow-lab for an A/B measurement)")
         for en in engines:
             en.close()
         return dict(pops=pops, steps=steps, elapsed=elapsed, d=d, st1=st1, tree_busy=tree_busy, tree_sum=tree_sum,

@@ -149,6 +149,10 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games);
 int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_t* active_slots);
 int sprl_engine_collect(sprl_engine* e, sprl_records* out);
 void sprl_records_free(sprl_records* r);
+/* Network evaluations queued by each of the first `num_games` games of the current / last self-play run (a leaf that reaches
+ * GridNetwork::evaluate in the reference, networks/GridNetwork.hpp:72-107; game index = the order the games were started in).
+ * The per-game view of sprl_stats.nn_evals: what a distributional comparison with the reference's selfPlay needs. */
+int sprl_engine_game_evals(sprl_engine* e, uint32_t* out, int32_t num_games);
 
 /* Finished-game records WITHOUT a host copy (after sprl_engine_step has reported every game done, instead of / before
  * sprl_engine_collect).  All pointers are DEVICE memory owned by the caller.

@@ -117,6 +117,7 @@ struct HeadArgs {
     const float *vfc2_w, *vfc2_b;    // [HID], [1]
     float *logits, *value;           // [batch][A], [batch]
     int A, HID;
+    unsigned magic_a, magic_h;       // ceil(2^20 / A), ceil(2^20 / HID): t / A == (t * magic_a) >> 20 for t < 512
 };
 // HEADS = 2 task split: the policy contraction (<= 128 long) in four parts, the hidden layer's (<= 64) in two; a task is one output
 // column x one part x the four boards of the workgroup, at most 32 weights long
@@ -414,57 +415,53 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
     // the partial sums go through LDS.  Task A of thread t: policy task t (part t / A, column t % A); task B: hidden task t (half
     // t / HID, unit t % HID) for t < 2 HID, else policy task 256 + t - 2 HID.  Every load is unconditional on a clamped index (no
     // branch per load), what lies outside the task is replaced by zero.
-    float fwa[HEADS == 2 ? FC_LP : 1], fwb[HEADS == 2 ? FC_LP : 1];
-    int qa0 = -1, qb0 = -1, fca = 0, fcb = 0, fkqa = 0, fkqb = 0;      // first contraction index (-1: no task), column, part
+    constexpr int LP = HEADS == 2 ? (PIN + 3) / 4 : 1, LV = HEADS == 2 ? (VIN + 1) / 2 : 1;      // task lengths (<= FC_LP)
+    float fwa[LP], fwh[LV], fwc[LP];                  // weights of: policy task tid, hidden task tid, policy task 256 + tid - 2 HID
+    int qa0 = -1, qh0 = -1, qc0 = -1, fca = 0, fch = 0, fcc = 0, fkqa = 0, fkqh = 0, fkqc = 0;     // first index (-1: no task), column, part
     float fc_bias[HEADS == 2 ? 5 : 1];
     if constexpr (HEADS == 2) {
+        // Buffer descriptors over the two weight matrices: a thread without the task gets an offset past the end, and so does a part
+        // that runs past the contraction - the range check answers with zeros.  All loads are issued back to back (scalar offset =
+        // row k of the part); nothing waits for them before the barrier below.
         const int A = ha.A, HID = ha.HID;
-        const int LP = (PIN + 3) >> 2, LV = (VIN + 1) >> 1;
-        const bool has_a = tid < 4 * A, is_hid = tid < 2 * HID;
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)ha.pfc_w, 0, (unsigned)(PIN * A) * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)ha.vfc1_w, 0, (unsigned)(VIN * HID) * 4u, 0x00020000);
+        constexpr int NONE = 0x7fff0000;
+        // t / A and t / HID for t < 512 without an integer division: multiply by ceil(2^20 / d) (exact for t * d < 2^20)
+        const unsigned ma = ha.magic_a, mh = ha.magic_h;
+        const bool has_a = tid < 4 * A, has_h = tid < 2 * HID;
         const int t2 = 256 + tid - 2 * HID;
-        const bool has_b2 = !is_hid && t2 < 4 * A;
-        fkqa = has_a ? tid / A : 0;
+        const bool has_c = !has_h && t2 < 4 * A;
+        fkqa = has_a ? (int)(((unsigned)tid * ma) >> 20) : 0;
         fca = has_a ? tid - fkqa * A : 0;
         qa0 = has_a ? fkqa * LP : -1;
-        {
-            const float* wp = ha.pfc_w + fca;
-            const int q0 = has_a ? qa0 : 0;
+        fkqh = has_h ? (int)(((unsigned)tid * mh) >> 20) : 0;
+        fch = has_h ? tid - fkqh * HID : 0;
+        qh0 = has_h ? fkqh * LV : -1;
+        fkqc = has_c ? (int)(((unsigned)t2 * ma) >> 20) : 0;
+        fcc = has_c ? t2 - fkqc * A : 0;
+        qc0 = has_c ? fkqc * LP : -1;
+        const int voa = has_a ? (qa0 * A + fca) * 4 : NONE, voh = has_h ? (qh0 * HID + fch) * 4 : NONE, voc = has_c ? (qc0 * A + fcc) * 4 : NONE;
+        // a wave none of whose threads has a task kind skips that kind's loads (wave-uniform: Othello - waves 0, 1 take the hidden
+        // layer, wave 2 the four left-over policy tasks)
+        const int w0 = wave * 64;
+        if (w0 < 4 * A) {
 #pragma unroll
-            for (int k = 0; k < FC_LP; ++k) {
-                const int q = q0 + k;
-                const float v = wp[(q < PIN ? q : PIN - 1) * A];
-                fwa[k] = (has_a && k < LP && q < PIN) ? v : 0.0f;
-            }
+            for (int k = 0; k < LP; ++k) fwa[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, voa, k * A * 4, 0));
         }
-        if (is_hid) {                                   // (wave-uniform when HID = 64: waves 0, 1 take the hidden layer)
-            fkqb = tid / HID;
-            fcb = tid - fkqb * HID;
-            qb0 = fkqb * LV;
-            const float* wp = ha.vfc1_w + fcb;
+        if (w0 < 2 * HID) {
 #pragma unroll
-            for (int k = 0; k < FC_LP; ++k) {
-                const int q = qb0 + k;
-                const float v = wp[(q < VIN ? q : VIN - 1) * HID];
-                fwb[k] = (k < LV && q < VIN) ? v : 0.0f;
-            }
-        } else {
-            fkqb = has_b2 ? t2 / A : 0;
-            fcb = has_b2 ? t2 - fkqb * A : 0;
-            qb0 = has_b2 ? fkqb * LP : -1;
-            const float* wp = ha.pfc_w + fcb;
-            const int q0 = has_b2 ? qb0 : 0;
+            for (int k = 0; k < LV; ++k) fwh[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voh, k * HID * 4, 0));
+        }
+        if (w0 + 63 >= 2 * HID && 256 + w0 - 2 * HID < 4 * A) {
 #pragma unroll
-            for (int k = 0; k < FC_LP; ++k) {
-                const int q = q0 + k;
-                const float v = wp[(q < PIN ? q : PIN - 1) * A];
-                fwb[k] = (has_b2 && k < LP && q < PIN) ? v : 0.0f;
-            }
+            for (int k = 0; k < LP; ++k) fwc[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, voc, k * A * 4, 0));
         }
         const int c64 = tid & 63;
         fc_bias[0] = ha.pfc_b[c64 < A ? c64 : 0];
         fc_bias[1] = ha.pfc_b[c64 + 64 < A ? c64 + 64 : 0];
-        fc_bias[2] = c64 < HID ? ha.vfc1_b[c64 < HID ? c64 : 0] : 0.0f;
-        fc_bias[3] = c64 < HID ? ha.vfc2_w[c64 < HID ? c64 : 0] : 0.0f;
+        fc_bias[2] = ha.vfc1_b[c64 < HID ? c64 : 0];
+        fc_bias[3] = ha.vfc2_w[c64 < HID ? c64 : 0];
         fc_bias[4] = ha.vfc2_b[0];
     }
     __syncthreads();
@@ -500,11 +497,11 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         const f4* const mq = (const f4*)maps;
         float* const pp = lds;                          // [part 0..3][board][FC_MAXA]
         float* const hpart = lds + 4 * 4 * FC_MAXA;     // [half 0..1][board][64]
-        auto task = [&](int q0, const float (&w)[HEADS == 2 ? FC_LP : 1], int qmax) {
+        auto task = [&](int q0, const auto& w, int qmax) {
             f4 acc4 = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-            for (int k = 0; k < (HEADS == 2 ? FC_LP : 1); ++k) {
-                const int q = q0 + k < qmax ? q0 + k : qmax;      // (past the part: weight 0 times a finite map value)
+            for (int k = 0; k < (int)(sizeof(w) / sizeof(float)); ++k) {
+                const int q = q0 + k < qmax ? q0 + k : qmax;      // (past the contraction: weight 0 times a finite map value)
                 const f4 m = mq[q];
                 acc4[0] = __builtin_fmaf(m[0], w[k], acc4[0]);
                 acc4[1] = __builtin_fmaf(m[1], w[k], acc4[1]);
@@ -518,14 +515,15 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
 #pragma unroll
             for (int b = 0; b < 4; ++b) pp[(fkqa * 4 + b) * FC_MAXA + fca] = r[b];
         }
-        if (tid < 2 * HID) {
-            const f4 r = task(PIN + qb0, fwb, PIN + VIN - 1);
+        if (qh0 >= 0) {
+            const f4 r = task(PIN + qh0, fwh, PIN + VIN - 1);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) hpart[(fkqb * 4 + b) * 64 + fcb] = r[b];
-        } else if (qb0 >= 0) {
-            const f4 r = task(qb0, fwb, PIN - 1);
+            for (int b = 0; b < 4; ++b) hpart[(fkqh * 4 + b) * 64 + fch] = r[b];
+        }
+        if (qc0 >= 0) {
+            const f4 r = task(qc0, fwc, PIN - 1);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) pp[(fkqb * 4 + b) * FC_MAXA + fcb] = r[b];
+            for (int b = 0; b < 4; ++b) pp[(fkqc * 4 + b) * FC_MAXA + fcc] = r[b];
         }
         __syncthreads();
         const int b = wave, c64 = lane;                 // thread = (board, column): the wave of a board reduces its hidden layer
@@ -1105,6 +1103,8 @@ extern "C" int sprl_wino_conv64_heads_fc(const float* x, const float* u, const f
     ha.hw = hw; ha.hb = hb;
     ha.pfc_w = pfc_w; ha.pfc_b = pfc_b; ha.vfc1_w = vfc1_w; ha.vfc1_b = vfc1_b; ha.vfc2_w = vfc2_w; ha.vfc2_b = vfc2_b;
     ha.logits = logits; ha.value = value; ha.A = A; ha.HID = HID;
+    ha.magic_a = ((1u << 20) + (unsigned)A - 1u) / (unsigned)A;
+    ha.magic_h = ((1u << 20) + (unsigned)HID - 1u) / (unsigned)HID;
     return launch_conv64<2>(x, u, scale, shift, res, nullptr, batch, H, W, 1, batch_dev, ha, stream);
 }
 

@@ -546,6 +546,7 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
         ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
         ok = ok && (P.rec_offsets = (int32_t*)dev_alloc(e, ((size_t)num_games + 1) * sizeof(int32_t)));
         ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
+        ok = ok && (P.rec_evals = (uint32_t*)dev_alloc(e, (size_t)num_games * sizeof(uint32_t)));
         if (!ok) return fail(SPRL_E_DEVICE, std::string("record allocation failed (") + be::last_error() + ")");
     }
     e->rec_total = -1;
@@ -577,6 +578,7 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
     rc |= be::dmemset(P.leaf_count, 0, (size_t)P.num_slots * sizeof(uint32_t));
     rc |= be::dmemset(P.leaf_offset, 0, (size_t)P.num_slots * sizeof(uint32_t));
     rc |= be::dmemset(P.rec_nplies, 0, (size_t)num_games * sizeof(int32_t));
+    rc |= be::dmemset(P.rec_evals, 0, (size_t)num_games * sizeof(uint32_t));
     rc |= be::dmemset(P.rec_pdf, 0, np * (size_t)e->g.A * sizeof(float));
     rc |= be::sync();
     if (rc) return fail(SPRL_E_DEVICE, be::last_error());
@@ -684,6 +686,15 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
     if (games_done) *games_done = (int32_t)c.games_done;
     if (active_slots) *active_slots = (int32_t)c.active_slots;
     return check_device_error(e, c);
+}
+
+// network evaluations queued by each game of the current / last self-play run (game index = the order games were started in)
+int sprl_engine_game_evals(sprl_engine* e, uint32_t* out, int32_t num_games) {
+    if (!e || !out) return fail(SPRL_E_CONFIG, "null argument");
+    if (!e->P.rec_evals || num_games < 0 || num_games > e->num_games) return fail(SPRL_E_STATE, "no self-play run with that many games");
+    be::bind(e->cfg.device, e->stream);
+    if (be::sync() != 0 || be::d2h(out, e->P.rec_evals, (size_t)num_games * sizeof(uint32_t)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+    return 0;
 }
 
 int sprl_engine_collect(sprl_engine* e, sprl_records* out) {

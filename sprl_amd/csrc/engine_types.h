@@ -149,6 +149,7 @@ struct EngineParams {
     int32_t* rec_nplies;
     int32_t* rec_offsets;   // [num_games + 1] exclusive prefix sum of rec_nplies (records_kernel.h), filled by the records scan
     int8_t* rec_winner;
+    uint32_t* rec_evals;    // [num_games] network evaluations each game queued (self-play runs; null in match play)
     Counters* counters;
 };
 

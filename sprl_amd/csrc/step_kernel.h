@@ -648,6 +648,7 @@ SPRL_DEV void select_batch(const EngineParams& P, Game& g, int slot, GameCtl* ct
         }
     }
     g.d_nn_evals += (uint32_t)g.n_leaves;
+    if (P.rec_evals && g.n_leaves && wv::lane() == 0) P.rec_evals[g.game_id] += (uint32_t)g.n_leaves;    // (one wave owns the game)
     SPRL_TOC(g.cyc_leafio, t_io);
 }
 

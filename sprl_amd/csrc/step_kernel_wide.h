@@ -821,6 +821,7 @@ SPRL_DEV void select_batch(const EngineParams& P, GameW& g, int slot, GameCtl* c
         }
     }
     g.d_nn_evals += (uint32_t)g.n_leaves;
+    if (P.rec_evals && g.n_leaves && wv::lane() == 0) P.rec_evals[g.game_id] += (uint32_t)g.n_leaves;    // (one wave owns the game)
 }
 
 // arena compaction: Cheney copy of the live subtree into a spare arena (same protocol as step_kernel.h)

@@ -109,6 +109,7 @@ def load_library(path=None):
     L.sprl_engine_set_model_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.sprl_engine_set_forward.argtypes = [C.c_void_p, FORWARD_FN, C.c_void_p]
     L.sprl_engine_evaluator_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    L.sprl_engine_game_evals.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.sprl_engine_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Records)]
     L.sprl_engine_begin.argtypes = [C.c_void_p, C.c_int32]
     L.sprl_engine_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -251,9 +252,15 @@ class Engine:
         self._check(self._lib.sprl_engine_set_forward(self._h, self._cb, None))
 
     def evaluator_info(self):
-        buf = C.create_string_buffer(256)
-        self._check(self._lib.sprl_engine_evaluator_info(self._h, buf, 256))
+        buf = C.create_string_buffer(768)
+        self._check(self._lib.sprl_engine_evaluator_info(self._h, buf, 768))
         return buf.value.decode()
+
+    def game_evals(self, num_games):
+        """Network evaluations queued by each of the first `num_games` games of the current / last self-play run."""
+        out = np.zeros(num_games, np.uint32)
+        self._check(self._lib.sprl_engine_game_evals(self._h, out.ctypes.data, num_games))
+        return out
 
     def run(self, num_games):
         rec = Records()

@@ -224,6 +224,31 @@ def test_g9b_baseline_shape_network_contract(golden):
         assert np.abs(g[f"logits{gi}"] - g[f"logits_f64_{gi}"]).max() < max(5e-6, 1e-6 * scale)
 
 
+def test_g9c_go_shape_network_contract(golden):
+    """The Go-shape networks of BASELINE configs 4 / 5 (6 blocks x 64 channels, 17 planes; scripts/go_controller.py:44-45): our
+    GridResNet with netfill weights and netfill's Go-like inputs == the reference's BasicGridNetwork outputs captured in g9c
+    (CPU fp32, same PyTorch kernels) - what the -m gpu test then holds the hand-written path to."""
+    import sys
+    import torch
+    from sprl_amd.network import GridResNet
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import netfill
+    g = golden("g9c_go_networks.npz")
+    seed = int(g["seed"][0])
+    assert int(g["blocks"][0]) == 6 and int(g["channels"][0]) == 64 and int(g["history"][0]) == 8
+    for width, actions in ((9, 82), (19, 362)):
+        x = torch.from_numpy(netfill.go_like_inputs(int(g[f"n{width}"][0]), width, 8, seed + width))
+        assert x.shape[1] == 17 and float(x.max()) == 1.0
+        for gi, gain in enumerate(g["gains"]):
+            net = netfill.fill_state_dict(GridResNet(width, width, actions, 8, 6, 64), seed + 100 * width + gi, float(gain)).eval()
+            with torch.no_grad():
+                lo, va = net(x)
+            scale = float(np.abs(g[f"logits{width}_{gi}"]).max())
+            np.testing.assert_allclose(lo.numpy(), g[f"logits{width}_{gi}"], atol=max(1e-5, 1e-6 * scale), rtol=0)
+            np.testing.assert_allclose(va.numpy(), g[f"value{width}_{gi}"], atol=1e-5, rtol=0)
+            assert np.abs(g[f"logits{width}_{gi}"] - g[f"logits{width}_f64_{gi}"]).max() < max(1e-5, 1e-6 * scale)
+
+
 @pytest.mark.skipif(not pyref.available(), reason="prebuilt reference library not present")
 @pytest.mark.parametrize("game,kind,trav,mb,mq,alpha,ngames", [
     ("othello", 0, 200, 8, 4, 0.3, 2), ("othello", 1, 100, 8, 4, 0.3, 2), ("othello", 0, 64, 1, 1, 0.3, 1),
