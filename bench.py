@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--resign-min-ply", type=int, default=-1, help="default 0 (go19: 60)")
     ap.add_argument("--allow-lab", action="store_true",
                     help="A/B measurements only: accept SPRL_* lab switches (the JSON line then names them in config.evaluator)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="othello: skip the bounded Go 9x9 / Go 19x19 samples (BASELINE configs 4 / 5) that follow the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
@@ -236,9 +238,11 @@ def main():
 
     stream_cursor = [1 + rank * (1 << 24)]      # unique RNG streams for every game of every step of every rank and pass
 
-    def measure(pops, steps, warmup):
+    def measure(pops, steps, warmup, profile_mode=1):
         """One timed region: `pops` engines (each on its own HIP stream and host thread when pops > 1) play `steps` steps of
-        `games` games per GPU.  Returns the wall time, the counter deltas and the busy times of the two profiled kernels."""
+        `games` games per GPU.  Returns the wall time, the counter deltas and the busy times of the two profiled kernels.
+        profile_mode 1: one HIP-event pair around the trunk convolutions of a forward (the timed region); 2: one pair per
+        convolution launch (kernel durations, for the one-population pass outside the timed region)."""
         if args.concurrent % pops or games % pops:
             raise SystemExit("--populations must divide --concurrent and --games")
         engines = []
@@ -247,7 +251,7 @@ def main():
             cfg = E.default_config(G["engine"], lib, device=local_rank, concurrent_games=args.concurrent // pops,
                                    num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap,
                                    stream_base=stream_cursor[0],
-                                   profile=0 if args.no_profile else 1, own_stream=1 if pops > 1 else 0,
+                                   profile=0 if args.no_profile else profile_mode, own_stream=1 if pops > 1 else 0,
                                    resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
             stream_cursor[0] += (games // pops) * (steps + warmup + 2)
             en = E.Engine(cfg, lib)
@@ -363,9 +367,9 @@ def main():
             en.close()
         return dict(pops=pops, steps=steps, elapsed=elapsed, d=d, st1=st1, tree_busy=tree_busy, tree_sum=tree_sum,
                     conv_busy=conv_busy, conv_sum=conv_sum, t_load=t_load, gather_s=gather_s[0], shard_bytes=shard_bytes[0],
-                    evaluator=info, verified=verified)
+                    evaluator=info, verified=verified, profile_mode=profile_mode)
 
-    def rooflines(M):
+    def rooflines(M, G=G, game=args.game, blocks=None):
         """(roofline of the trunk convolution or None, roofline of the tree kernel or None) of one measure() result.
         achieved = algorithmic bytes / flops of all launches / time the kernel was executing.  One engine: that time is the sum
         of the launch durations (= launches x avg_launch_ms).  Several engines (--populations): their launches overlap on
@@ -379,7 +383,7 @@ def main():
         achieved = d["traversals"] * bpt / (tree_time_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "tree_kernel_traffic.json")
-        if os.path.exists(tpath) and args.game == "othello":   # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
+        if os.path.exists(tpath) and game == "othello":   # PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh)
             with open(tpath) as tf:
                 traffic = json.load(tf).get("hbm_bytes_per_launch")
         tree = {"bound": "hbm", "kernel": f"step_kernel ({G['label']}: select/expand/backup/re-root)",
@@ -411,7 +415,9 @@ def main():
         ctraffic = None
         boards_per_launch = d["conv_boards"] / max(1, d["conv_launches"])
         cpath = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
-        if os.path.exists(cpath) and args.game == "othello":
+        if not os.path.exists(cpath) or game != "othello":
+            cpath = os.path.join(ROOT, "profiles", f"conv_kernel_traffic_{game}.json")
+        if os.path.exists(cpath):
             # PMC passes (separate rocprofv3 runs with one population, tools/profile_round.sh): HBM bytes per launch at the
             # profiled boards per launch; the kernel's traffic is proportional to the boards of a launch (0.99 x algorithmic)
             with open(cpath) as tf_:
@@ -428,6 +434,9 @@ def main():
                 "overlap": (M["conv_sum"] / M["conv_busy"]) if M["conv_busy"] else None,
                 "avg_launch_ms": d["conv_ms"] / max(1, d["conv_launches"]),
                 "boards_per_launch": boards_per_launch,
+                "timing": ("per_launch_events" if M.get("profile_mode", 1) == 2 else
+                           f"bracket_{2 * (blocks or args.blocks)}_launches (one HIP-event pair around the trunk convolutions of a forward: "
+                           "avg_launch_ms = bracket / launches, it includes the gaps between the launches"),
                 "flop_per_board": flop_per_board, "tile": f"F({m_tile}x{m_tile},3x3), {tiles} tiles x {npos} positions per board",
                 "useful_cells_fraction": useful_cells, "frac_useful": tf / MFMA_F32_PEAK_TF * useful_cells,
                 "direct_conv_equivalent_tflops": tf * (9.0 * m_tile * m_tile / npos) * useful_cells, "populations": mp}
@@ -440,40 +449,111 @@ def main():
     # the same kernels with nothing running beside them: a separate untimed-for-`value` pass with ONE population (one step)
     M1 = None
     if pops > 1 and not args.no_profile and not args.no_alone_pass and args.game == "othello":     # (a Go step is minutes long)
-        M1 = measure(1, 1, 0)
+        M1 = measure(1, 1, 0, profile_mode=2)       # per-launch event pairs: kernel durations (comparable with rocprofv3's averages)
 
-    def alone_sample(rounds, warm):
-        """Go configurations: a BOUNDED one-population sample instead of a whole extra step - one engine with the resident games of
-        one population (the launch geometry of the timed run), `warm` search rounds untimed, then `rounds` rounds.  Same dict as
-        measure(); games are between move warm / 100 and (warm + rounds) / 100 (a move is num_traversals / max_queue rounds)."""
-        cfg = E.default_config(G["engine"], lib, device=local_rank, concurrent_games=args.concurrent // pops,
-                               num_traversals=args.traversals, seed=args.seed, node_cap=args.node_cap, stream_base=stream_cursor[0],
-                               profile=1, own_stream=0, resign_threshold=args.resign_threshold, resign_min_ply=args.resign_min_ply)
-        stream_cursor[0] += 2 * (games // pops)
-        en = E.Engine(cfg, lib)
-        en.set_model(model_path if model_path else args.model)
-        en.begin(args.concurrent // pops)
-        done = 0
-        while done < warm:
-            en.step(min(args.rounds_per_call, warm - done))
-            done += min(args.rounds_per_call, warm - done)
-        st0 = {k: v for k, v in en.stats().items() if isinstance(v, (int, float))}
+    def sample_rounds(game, pops_s, concurrent, rounds, warm, resign_threshold=0.0, resign_min_ply=0, model=None, profile_mode=1):
+        """A BOUNDED sample of a configuration: `pops_s` engines (own streams and host threads when > 1) with `concurrent` resident
+        games in all, `warm` search rounds untimed (first touch of the arenas, the opening rounds), then `rounds` rounds timed
+        between barriers.  A move is num_traversals / max_queue rounds, so the games are between move warm / that and
+        (warm + rounds) / that.  Same dict as measure()."""
+        import threading
+        Gs = GAMES[game]
+        engines = []
+        for p in range(pops_s):
+            cfg = E.default_config(Gs["engine"], lib, device=local_rank, concurrent_games=concurrent // pops_s,
+                                   num_traversals=Gs["traversals"] if game != args.game else args.traversals, seed=args.seed,
+                                   node_cap=args.node_cap if game == args.game else 0, stream_base=stream_cursor[0],
+                                   profile=profile_mode, own_stream=1 if pops_s > 1 else 0,
+                                   resign_threshold=resign_threshold, resign_min_ply=resign_min_ply)
+            stream_cursor[0] += 2 * (concurrent // pops_s)
+            en = E.Engine(cfg, lib)
+            en.set_model(model)
+            en.begin(concurrent // pops_s)
+            engines.append(en)
+
+        def run(en, n):
+            done = 0
+            while done < n:
+                k = min(args.rounds_per_call, n - done)
+                en.step(k)
+                done += k
+
+        def run_all(n):
+            if pops_s == 1:
+                run(engines[0], n)
+                return
+            ths = [threading.Thread(target=run, args=(en, n)) for en in engines]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+
+        def all_stats():
+            tot = {}
+            for en in engines:
+                for k, v in en.stats().items():
+                    if isinstance(v, (int, float)):
+                        tot[k] = max(tot.get(k, 0), v) if k in ("max_nodes_in_arena", "cyc_max_slot_launch") else tot.get(k, 0) + v
+            return tot
+
+        run_all(warm)
+        st0 = all_stats()
+        lib.sprl_profile_busy_reset()
         barrier()
         t0 = time.perf_counter()
-        done = 0
-        while done < rounds:
-            en.step(min(args.rounds_per_call, rounds - done))
-            done += min(args.rounds_per_call, rounds - done)
-        st1 = {k: v for k, v in en.stats().items() if isinstance(v, (int, float))}
+        run_all(rounds)
         barrier()
         elapsed = time.perf_counter() - t0
+        st1 = all_stats()
+        tree_busy, tree_sum = E.profile_busy(lib, 0)
+        conv_busy, conv_sum = E.profile_busy(lib, 1)
         d = {k: st1[k] - st0[k] for k in st1 if k not in ("max_nodes_in_arena", "hbm_bytes")}
-        en.close()
-        return dict(pops=1, steps=0, elapsed=elapsed, d=d, st1=st1, tree_busy=None, tree_sum=None, conv_busy=None, conv_sum=None)
+        info = engines[0].evaluator_info()
+        for en in engines:
+            ei = en.evaluator_info()
+            if not args.allow_lab and ("hand-written gfx950 CNN" not in ei or ei.count("lab=[]") != 2):
+                raise SystemExit(f"bench.py: refusing to report a sample on a non-default evaluator path: {ei!r}")
+            en.close()
+        return dict(pops=pops_s, steps=0, elapsed=elapsed, d=d, st1=st1, tree_busy=tree_busy if pops_s > 1 else None,
+                    tree_sum=tree_sum if pops_s > 1 else None, conv_busy=conv_busy if pops_s > 1 else None,
+                    conv_sum=conv_sum if pops_s > 1 else None, evaluator=info, profile_mode=profile_mode)
 
     MA = None
     if pops > 1 and not args.no_profile and not args.no_alone_pass and args.game != "othello" and model_path:
-        MA = alone_sample(1500 if args.game == "go9" else 600, 1500 if args.game == "go9" else 600)
+        n_alone = 1500 if args.game == "go9" else 600
+        MA = sample_rounds(args.game, 1, args.concurrent // pops, n_alone, n_alone, args.resign_threshold, args.resign_min_ply,
+                           model=model_path, profile_mode=2)
+
+    # BASELINE configs 4 / 5 inside the DEFAULT run (VERDICT r3 #5): after the Othello timed region, bounded two-population samples of
+    # Go 9x9 and Go 19x19 at their stated budgets (1600 iterations/move, batch 16 / queue 8, the 6 x 64 network, 4096 / 2048
+    # resident games), a fixed number of search rounds each - evaluations/s, traversals/s, plies/s and the rooflines of their
+    # dominant kernels land in the driver-run record, not only in builder-run files
+    secondary = None
+    if args.game == "othello" and args.model == "cnn" and world == 1 and not args.no_secondary and not args.no_profile:
+        secondary = {}
+        for sg, warm_r, timed_r in (("go9", 200, 1000), ("go19", 100, 400)):
+            Gs = GAMES[sg]
+            t_s0 = time.perf_counter()
+            mp_s = trace_to_file(make_network(Gs["engine"], Gs["blocks"], args.channels, seed=0),
+                                 os.path.join(tmpdir, f"traced_{sg}.pt"), Gs["engine"])
+            # resign: the extension cannot fire before ply 60 (go19's resign_min_ply) and a bounded sample from the start position
+            # covers the first moves only, so this sample IS the resign-off regime (reference behaviour, SURVEY Q12)
+            Ms = sample_rounds(sg, 2, Gs["concurrent"], timed_r, warm_r, model=mp_s)
+            cs, ts = rooflines(Ms, Gs, sg, Gs["blocks"])
+            ds = Ms["d"]
+            rounds_per_move = Gs["traversals"] / int(Gs["bq"].split("/")[1])
+            secondary[sg] = {
+                "workload": f"{Gs['label']}, {Gs['traversals']} UCT iters/move, {Gs['concurrent']} concurrent games, batch {Gs['bq'].split('/')[0]}/queue "
+                            f"{Gs['bq'].split('/')[1]}, {Gs['sym']}, {Gs['noise']}, traced CNN {Gs['blocks']}x{args.channels} fp32, 2 populations, resign off",
+                "sample": f"{warm_r} untimed + {timed_r} timed search rounds per population from the start position (moves "
+                          f"{warm_r / rounds_per_move:.1f} .. {(warm_r + timed_r) / rounds_per_move:.1f} of every game)",
+                "seconds": Ms["elapsed"], "wall_seconds_incl_setup": time.perf_counter() - t_s0,
+                "nn_evals_per_sec": ds["nn_evals"] / Ms["elapsed"], "traversals_per_sec": ds["traversals"] / Ms["elapsed"],
+                "expansions_per_sec": ds["expansions"] / Ms["elapsed"], "plies_per_sec": ds["plies"] / Ms["elapsed"],
+                "moves_per_game_per_sec": ds["plies"] / Ms["elapsed"] / Gs["concurrent"],
+                "hbm_gib": Ms["st1"]["hbm_bytes"] / 2**30, "max_nodes_in_arena": Ms["st1"]["max_nodes_in_arena"],
+                "nodes_recycled_share": ds["nodes_recycled"] / max(1, ds["nodes_created"]), "compactions": ds["compactions"],
+                "evaluator": Ms["evaluator"], "roofline": cs, "roofline_tree": ts}
 
     # what the collective backend really saw: world size, backend name and every rank's device, gathered from the ranks themselves
     me = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "name": torch.cuda.get_device_name(local_rank),
@@ -535,10 +615,21 @@ def main():
             out["roofline"] = tree_rl
         if M1 is not None:
             c1, t1 = rooflines(M1)
+            if conv_rl is not None and c1 is not None:
+                # the kernel's own duration (one event pair per launch, nothing else on the GPU), measured after the timed region:
+                # the figure that is comparable with the rocprofv3 --kernel-trace average under profiles/
+                out["roofline"]["kernel_only"] = {"avg_launch_ms": c1["avg_launch_ms"], "boards_per_launch": c1["boards_per_launch"],
+                                                  "achieved": c1["achieved"], "frac": c1["frac"], "timing": c1["timing"],
+                                                  "from": "one_population_pass"}
+            if tree_rl is not None and t1 is not None:
+                out["roofline_tree"]["kernel_only"] = {"avg_launch_ms": t1["avg_launch_ms"], "achieved": t1["achieved"], "frac": t1["frac"],
+                                                       "from": "one_population_pass"}
             out["one_population_pass"] = {
                 "what": "the same workload with ONE population (no kernel of another stream beside it), one step, after the timed "
                         "region: per-launch figures comparable to the rocprofv3 averages under profiles/",
                 "games_per_sec": games * world / M1["elapsed"], "roofline": c1, "roofline_tree": t1}
+        if secondary is not None:
+            out["secondary"] = secondary
         if MA is not None:
             ca, ta = rooflines(MA)
             out["one_population_sample"] = {

@@ -22,10 +22,12 @@ extern "C" {
 #define SPRL_E_CONFIG   (-1)  /* bad configuration value */
 #define SPRL_E_MODEL    (-2)  /* model file could not be loaded / evaluator plugin missing */
 #define SPRL_E_NODEPOOL (-3)  /* a game's node arena overflowed (raise node_cap / spare_arenas) */
-#define SPRL_E_DEVICE   (-4)  /* HIP error, no device, allocation failure */
+#define SPRL_E_DEVICE   (-4)  /* HIP error, no device */
 #define SPRL_E_STATE    (-5)  /* call sequence error */
 #define SPRL_E_IO       (-6)  /* file could not be written */
 #define SPRL_E_LIMIT    (-7)  /* game longer than max_plies / line deeper than the path buffer */
+#define SPRL_E_NOMEM    (-8)  /* device memory: the arenas (sprl_engine_create) or the record buffers of a run (sprl_engine_begin /
+                                 sprl_engine_run) do not fit - retry with fewer concurrent_games */
 
 /* SPRL_GO7: Go as the reference compiles it — 7x7, komi 9.0, 8-ply history, positional superko, depth cap 98
  * (games/GoNode.hpp:16-22) */
@@ -67,7 +69,9 @@ typedef struct sprl_config {
     uint64_t seed;             /* game g uses Random(seed, stream_base + g) (utils/random.hpp:92-103); a later run on the same
                                   engine continues the numbering (its game g: stream_base + games of earlier runs + g) */
     int32_t stream_base;       /* must be >= 1 */
-    int32_t profile;           /* 1: time every tree-kernel launch with HIP events on its stream */
+    int32_t profile;           /* 1: time every tree-kernel launch with HIP events on its stream, the trunk convolutions of a forward
+                                  with one pair around all of them; 2: one pair per convolution launch (kernel durations; for samples
+                                  outside a timed region - two more queue packets per launch) */
     int32_t own_stream;        /* 1: the engine works on a private non-blocking HIP stream instead of the null stream, so that
                                   several engines driven from different host threads overlap on one GPU */
     float resign_threshold;    /* NOT in the reference (BASELINE config 5), 0 = off: after a search the side to move resigns

@@ -418,7 +418,7 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
     if (!ok) {
         std::string m = std::string("device allocation failed (") + be::last_error() + ")";
         sprl_engine_destroy(e);
-        return fail(SPRL_E_DEVICE, m);
+        return fail(SPRL_E_NOMEM, m);
     }
     P.nn_logits = e->nn_logits;
     P.nn_value = e->nn_value;
@@ -490,7 +490,7 @@ static int set_model_common(sprl_engine* e, const char* model, const void* bytes
         return fail(SPRL_E_CONFIG, "own_stream needs an evaluator that runs on the engine's stream: this network plugin has no "
                                    "sprl_torch_forward_on");
     }
-    if (e->cfg.profile && e->torch.profile_enable) e->torch.profile_enable(m, 1);
+    if (e->cfg.profile && e->torch.profile_enable) e->torch.profile_enable(m, e->cfg.profile == 2 ? 2 : 1);
     e->forward_cb = nullptr;
     e->eval_kind = SPRL_EVAL_NETWORK;
     return 0;
@@ -547,7 +547,7 @@ int sprl_engine_begin(sprl_engine* e, int32_t num_games) {
         ok = ok && (P.rec_offsets = (int32_t*)dev_alloc(e, ((size_t)num_games + 1) * sizeof(int32_t)));
         ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
         ok = ok && (P.rec_evals = (uint32_t*)dev_alloc(e, (size_t)num_games * sizeof(uint32_t)));
-        if (!ok) return fail(SPRL_E_DEVICE, std::string("record allocation failed (") + be::last_error() + ")");
+        if (!ok) return fail(SPRL_E_NOMEM, std::string("record allocation failed (") + be::last_error() + ")");
     }
     e->rec_total = -1;
     if (e->games_begun > 0) {                    // keep the search counters of the run that is being replaced
@@ -923,7 +923,7 @@ int sprl_match_play(const sprl_config* cfg, const sprl_match_agent* agent0, cons
     ok = ok && (P.match_actions = (int16_t*)dev_alloc(e, na * sizeof(int16_t)));
     ok = ok && (P.rec_nplies = (int32_t*)dev_alloc(e, (size_t)num_games * sizeof(int32_t)));
     ok = ok && (P.rec_winner = (int8_t*)dev_alloc(e, (size_t)num_games));
-    if (!ok) return done(fail(SPRL_E_DEVICE, std::string("match allocation failed (") + be::last_error() + ")"));
+    if (!ok) return done(fail(SPRL_E_NOMEM, std::string("match allocation failed (") + be::last_error() + ")"));
     P.num_games = num_games;
     std::vector<GameCtl> ctl((size_t)P.num_slots);
     memset(ctl.data(), 0, ctl.size() * sizeof(GameCtl));

@@ -139,6 +139,8 @@ busy::Log g_conv_busy;
 
 struct ConvProfile {
     bool on = false;
+    bool per_launch = false;             // mode 2: one event pair per convolution launch (kernel durations comparable with a profiler's
+                                         // per-kernel average; costs two queue packets per launch - never used in a timed region)
     std::vector<hipEvent_t> ev;          // pairs (start, end), resolved lazily
     double ms = 0.0;
     int64_t launches = 0, boards = 0;
@@ -346,7 +348,13 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                     at::Tensor& dst) {
         const int rc = sprl_wino_conv64_dev(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(),
                                             res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, stream);
-        if (prof) prof->note(B);
+        if (prof) {
+            prof->note(B);
+            if (prof->per_launch) {                  // close this launch's pair, open the next one's
+                prof->close((hipStream_t)stream);
+                prof->open((hipStream_t)stream);
+            }
+        }
         return rc == 0;
     };
     const int A0 = (int)n.pfc_w.size(1), HID0 = (int)n.vfc1_w.size(1);
@@ -473,7 +481,13 @@ bool forward_nchw(Model* mdl, const float* planes, int cap, int P, int H, int W,
     auto conv = [&](const float* src, const at::Tensor& u, const at::Tensor& sc, const at::Tensor& sh, const float* res, float* dst) {
         const int rc = sprl_wino_conv64_t_occ(src, u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(), res, dst, cap, H, W, 1, tile,
                                               mdl->sw.f3_occ, batch_dev, stream);
-        if (prof) prof->note(cap);
+        if (prof) {
+            prof->note(cap);
+            if (prof->per_launch) {
+                prof->close((hipStream_t)stream);
+                prof->open((hipStream_t)stream);
+            }
+        }
         return rc == 0;
     };
     for (const auto& b : n.blocks) {
@@ -718,7 +732,13 @@ void sprl_wino_transform_weights_t(const float* w, float* u, int tile) {
 }
 
 // profile mode: time every trunk-convolution launch with HIP events; totals since load (ms, launches, boards)
-void sprl_torch_profile_enable(void* handle, int on) { static_cast<Model*>(handle)->prof.on = on != 0; }
+// on = 1: one event pair around all trunk convolutions of a forward (what a timed run uses: the interval includes the few
+// microseconds between the launches); on = 2: one pair per convolution launch (kernel durations, for a sample outside a timed region)
+void sprl_torch_profile_enable(void* handle, int on) {
+    ConvProfile& p = static_cast<Model*>(handle)->prof;
+    p.on = on != 0;
+    p.per_launch = on == 2;
+}
 // time with >= 1 trunk-convolution launch executing, over all models of the process (busy_log.h); read after profile_read
 double sprl_torch_profile_busy(double* sum_ms) { return g_conv_busy.union_ms(sum_ms); }
 void sprl_torch_profile_busy_reset() { g_conv_busy.reset(); }

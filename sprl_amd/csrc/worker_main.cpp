@@ -159,6 +159,8 @@ int main(int argc, char** argv) {
     auto run_range = [&](const int first, const int count, const int pop) -> int {
     sprl_engine* eng = nullptr;
     int eng_sig[4] = { -1, -1, -1, -1 };                            // traversals, batch, queue, concurrent of the live engine
+    sprl_config eng_cfg;                                            // the configuration the live engine was created with
+    memset(&eng_cfg, 0, sizeof(eng_cfg));
     int next_stream = 1 + pop * (1 << 27);                          // disjoint RNG stream ranges per population
     auto fail = [&](const char* what) {
         fprintf(stderr, "%s: %s\n", what, sprl_last_error());
@@ -204,18 +206,30 @@ int main(int argc, char** argv) {
             for (;;) {
                 cfg.concurrent_games = conc;
                 rc = sprl_engine_create(&cfg, &eng);
-                if (rc != SPRL_E_DEVICE || conc <= 1 || !strstr(sprl_last_error(), "allocation")) break;
+                if (rc != SPRL_E_NOMEM || conc <= 1) break;
                 conc = (conc + 1) / 2;
             }
             if (rc != 0) return fail("engine");
             if (conc != wanted) printf("HBM holds %d of the %d games at once; the rest start as slots free up.\n", conc, wanted);
             eng_sig[0] = trav; eng_sig[1] = mb; eng_sig[2] = mq; eng_sig[3] = wanted;
+            eng_cfg = cfg;
         }
         next_stream += total;                // (an engine kept from the previous iteration continues its stream numbering itself)
         printf(model == "random" || model == "heuristic" ? "Using initial network...\n" : "Using traced PyTorch network...\n");
-        if (sprl_engine_set_model(eng, model.c_str()) != 0) return fail("model");
         sprl_records rec;
-        if (sprl_engine_run(eng, total, &rec) != 0) return fail("self-play");
+        for (;;) {
+            if (sprl_engine_set_model(eng, model.c_str()) != 0) return fail("model");
+            const int rc = sprl_engine_run(eng, total, &rec);
+            if (rc == 0) break;
+            // the record buffers of `total` games are allocated when the run begins: an engine whose arenas just fitted can still
+            // fail THERE - the same back-off, with a fresh engine of half the resident games
+            if (rc != SPRL_E_NOMEM || eng_cfg.concurrent_games <= 1) return fail("self-play");
+            sprl_engine_destroy(eng);
+            eng = nullptr;
+            eng_cfg.concurrent_games = (eng_cfg.concurrent_games + 1) / 2;
+            if (sprl_engine_create(&eng_cfg, &eng) != 0) return fail("engine");
+            printf("Record buffers did not fit beside the arenas: %d games resident at once.\n", eng_cfg.concurrent_games);
+        }
         for (int t = 0; t < cover; ++t) {
             sprl_records part;
             if (sprl_records_slice(&rec, t * games, games, &part) != 0) {

@@ -123,14 +123,17 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
         perm = torch.randperm(n, device=device, generator=generator)
         n_train = int((1.0 - cfg.val_fraction) * n)                              # :135-138
         train_idx, val_idx = perm[:n_train], perm[n_train:]
-        if train_idx.numel() == 0:
-            raise ValueError(f"train_network: this rank's shard has {n} samples, none left for training after the "
-                             f"{cfg.val_fraction:.0%} validation split")
         steps = (train_idx.numel() + cfg.batch_size - 1) // cfg.batch_size
-        if dist is not None:                                                     # same number of all-reduces on every rank
-            st = torch.tensor([steps], device=device)
+        smallest = train_idx.numel()
+        if dist is not None:                                                     # same number of all-reduces on every rank;
+            # the empty-shard error is agreed COLLECTIVELY in the same all-reduce: a rank that raised alone would
+            # leave the others blocked in this collective until the RCCL watchdog fires.  [max steps, -min training samples]
+            st = torch.tensor([steps, -train_idx.numel()], device=device)
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
-            steps = int(st.item())
+            steps, smallest = int(st[0].item()), -int(st[1].item())
+        if smallest == 0:
+            raise ValueError(f"train_network: a rank's shard (this rank's: {n} samples) leaves nothing for training after the "
+                             f"{cfg.val_fraction:.0%} validation split")
     model = net
     if dist is not None:
         from torch.nn.parallel import DistributedDataParallel
@@ -180,6 +183,7 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                 vp, vv, vn = gtp, gtv, gnb
             vp, vv = vp / max(1.0, vn), vv / max(1.0, vn)
             val_loss = vp + vv
+            nb = nb or 1                                                         # (an index_plan without training batches)
             history.append(dict(epoch=e, train_policy=tp / nb, train_value=tv / nb, val_policy=vp, val_value=vv))
             if val_loss < best_val:                                              # :210-219
                 best_val, best_epoch = val_loss, e

@@ -5,7 +5,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <stdio.h>
+
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <string>
 
 #include "../../sprl_amd/csrc/backend.h"
@@ -48,11 +52,43 @@ void block_entry_wide(void* arg, int block) {
 
 namespace be {
 const char* name() { return "cpu-simt-emulator (tests only)"; }
-const char* last_error() { return "emulator error"; }
+static const char* g_err = "emulator error";
+const char* last_error() { return g_err; }
 bool available(std::string*) { return true; }
 int init(int, std::string*) { return 0; }
-void* dmalloc(size_t bytes) { return calloc(1, bytes); }
-void dfree(void* p) { free(p); }
+// Test hook of the EMULATOR only (never in the product library): SPRL_EMU_HBM_BYTES bounds the live "device" memory so that the
+// host code's out-of-memory paths (SPRL_E_NOMEM, the worker's back-off) can be exercised on the CPU; SPRL_EMU_HBM_REPORT prints the
+// high-water mark at exit.
+static std::mutex g_mem_mu;
+static std::map<void*, size_t> g_mem_live;
+static size_t g_mem_now = 0, g_mem_peak = 0;
+static void mem_report() { fprintf(stderr, "emu hbm peak bytes: %zu\n", g_mem_peak); }
+void* dmalloc(size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_mem_mu);
+    static const char* lim = getenv("SPRL_EMU_HBM_BYTES");
+    static const bool report = getenv("SPRL_EMU_HBM_REPORT") != nullptr && atexit(mem_report) == 0;
+    (void)report;
+    if (lim && g_mem_now + bytes > (size_t)strtoull(lim, nullptr, 10)) {
+        g_err = "emulated HBM exhausted";
+        return nullptr;
+    }
+    void* p = calloc(1, bytes);
+    if (p) {
+        g_mem_live[p] = bytes;
+        g_mem_now += bytes;
+        if (g_mem_now > g_mem_peak) g_mem_peak = g_mem_now;
+    }
+    return p;
+}
+void dfree(void* p) {
+    std::lock_guard<std::mutex> lock(g_mem_mu);
+    auto it = g_mem_live.find(p);
+    if (it != g_mem_live.end()) {
+        g_mem_now -= it->second;
+        g_mem_live.erase(it);
+    }
+    free(p);
+}
 int h2d(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return 0; }
 int d2h(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return 0; }
 int dmemset(void* dst, int v, size_t n) { memset(dst, v, n); return 0; }

@@ -181,3 +181,41 @@ def test_ddp_training_with_unequal_shards_stays_in_step(tmp_path):
     assert int(a["best_epoch"]) == int(b["best_epoch"]) and int(a["epochs"]) == int(b["epochs"])
     assert np.array_equal(a["val"], b["val"])
     assert np.array_equal(a["best"], b["best"]) and np.array_equal(a["live"], b["live"])
+
+
+DDP_EMPTY_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from sprl_amd import trainer as T
+from sprl_amd.network import GridResNet
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+torch.manual_seed(3)
+net = GridResNet(6, 7, 7, 1, 1, 8)
+n = 200 if rank == 0 else 1                             # rank 1: one sample, nothing left for training after the split
+s = (torch.rand(n, 3, 6, 7) > 0.5).float()
+d = torch.softmax(torch.randn(n, 7), 1)
+o = torch.sign(torch.randn(n, 1))
+t = torch.ones(n, 1)
+cfg = T.TrainerConfig(batch_size=64, max_groups=1, epochs_per_group=1)
+try:
+    T.train_network(net, 0.01, (s, d, o, t), cfg, ddp=True)
+    code = 1
+except ValueError:
+    code = 0                                            # EVERY rank raises: nobody is left waiting in a collective
+dist.barrier(); dist.destroy_process_group()
+sys.exit(code)
+"""
+
+
+def test_ddp_empty_shard_is_an_error_on_every_rank(tmp_path):
+    """one rank's shard leaves no training samples.  The error is agreed in the step-count all-reduce, so BOTH ranks
+    raise - the rank with the full shard does not hang in the collective until the watchdog fires (world size 2, gloo)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ddp_empty.py"
+    script.write_text(DDP_EMPTY_SCRIPT.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    assert [p.wait(timeout=120) for p in procs] == [0, 0]

@@ -296,3 +296,34 @@ def test_native_worker_populations(tmp_path):
             assert np.load(d / "poprun_iteration_0_outcomes.npy").shape[0] == got.shape[0]
     assert subprocess.run([exe, "connect_four", "0", "4", "--num-tasks-const", "4", "--cover", "2", "--populations", "3"],
                           capture_output=True).returncode == 1               # more populations than covered tasks
+
+
+def test_native_worker_backs_off_when_device_memory_runs_out(tmp_path):
+    """SPRL_E_NOMEM is its own code, and the worker halves the resident games both when the ARENAS do not fit
+    (sprl_engine_create) and when the RECORD BUFFERS of the run do not fit beside them (sprl_engine_run allocates them) - the
+    second case used to end the worker.  The emulator library bounds its "device" memory (SPRL_EMU_HBM_BYTES, a hook of the
+    test build only).  Games do not depend on how many are resident, so every run writes the same bytes."""
+    import re
+    exe = _native_worker()
+    base = ["connect_four", "0", "4", "--cover", "1", "--num-tasks-const", "4", "--num-groups", "1", "--num-iters", "1", "--init-games", "48",
+            "--init-traversals", "12", "--init-max-batch", "8", "--init-max-queue", "4", "--seed", "5", "--concurrent", "4",
+            "--run-name", "memrun", "--evaluator-override", "random"]
+
+    def run(root, **env):
+        out = subprocess.run([exe] + base + ["--root", str(root)], capture_output=True, text=True, timeout=240,
+                             env=dict(os.environ, **env))
+        assert out.returncode == 0, (out.stdout, out.stderr)
+        d = root / "data" / "games" / "memrun" / "0" / "0"
+        return out, b"".join(open(d / f"memrun_iteration_0_{part}.npy", "rb").read() for part in ("states", "distributions", "outcomes"))
+
+    full, want = run(tmp_path / "a", SPRL_EMU_HBM_REPORT="1")
+    peak = int(re.search(r"emu hbm peak bytes: (\d+)", full.stderr).group(1))
+    assert "HBM holds" not in full.stdout and "Record buffers" not in full.stdout
+    # 1 KB short of the peak: the arenas of 4 resident games fit, the record buffers of the 48 games then do not
+    rec, got = run(tmp_path / "b", SPRL_EMU_HBM_BYTES=str(peak - 1024))
+    assert "Record buffers did not fit beside the arenas: 2 games resident at once." in rec.stdout, rec.stdout
+    assert got == want
+    # one game's arena (1.1 MB at this budget) less: the arenas of 4 resident games themselves do not fit
+    half, got = run(tmp_path / "c", SPRL_EMU_HBM_BYTES=str(peak - 1200 * 1024))
+    assert "HBM holds 2 of the 4 games at once" in half.stdout or "HBM holds 1 of the 4 games at once" in half.stdout, half.stdout
+    assert got == want
