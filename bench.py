@@ -273,27 +273,49 @@ def main():
                 assert sh["ply_offset"][-1] == sh["total_plies"] and abs(float(sh["pdfs"].sum()) - sh["total_plies"]) < 1e-2 * sh["total_plies"]
             return {"shards": len(un), "games": [int(sh["num_games"]) for sh in un], "plies": [int(sh["total_plies"]) for sh in un]}
 
-        def emit_records(en):
+        copy_stream = torch.cuda.Stream(device=dev)
+        pinned = {}                                 # (slot, bytes) -> pinned host buffer, reused from step to step
+        in_flight = []                              # device tensors whose copy to the host may still be running
+
+        def to_host_async(dev_tensors, slot0):
+            """Device shards -> pinned host memory on a SIDE stream: the copy of step k runs under the games of
+            step k + 1; the timed region ends with copy_stream.synchronize(), so every byte has arrived inside the bracket."""
+            copy_stream.wait_stream(torch.cuda.current_stream(dev))
+            outs = []
+            with torch.cuda.stream(copy_stream):
+                for i, t in enumerate(dev_tensors):
+                    key = (slot0 + i, t.numel())
+                    if key not in pinned:
+                        pinned[key] = torch.empty(t.numel(), dtype=torch.uint8, pin_memory=True)
+                    pinned[key].copy_(t, non_blocking=True)
+                    outs.append(pinned[key])
+            in_flight.append(dev_tensors)
+            if len(in_flight) > 2 * max(1, pops):
+                del in_flight[0]
+            return outs
+
+        def emit_records(en, slot):
             """The finished games' compact records, packed ON THE DEVICE from the engine's record buffers (records_kernel.h).
             N > 1: the packed shards are gathered to rank 0 by the collective backend on the tensors where they lie (RCCL: device
-            memory, no host bounce - SURVEY section 8e).  N = 1: the shard is copied to the host once (what a worker would write out)."""
+            memory, no host bounce - SURVEY section 8e).  Rank 0 (every rank at N = 1) then copies the bytes to the host - what a
+            worker would write out - on a side stream; they are DECODED after the timed region (verify_last_shards)."""
             plies, _, nbytes = en.records_info()
             shard = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             en.pack_records_into(shard.data_ptr(), nbytes)
             en.finish()
             shard_bytes[0] = nbytes
             if dist is None:
-                host = shard.cpu()
-                last_shards[:] = [host]
-                return int(host[:16].view(torch.int64)[1])            # head[1] = plies of the shard
-            # rank 0 receives the packed shards and copies the bytes to the host (as at N = 1); they are DECODED after the timed
-            # region (verify_last_shards), not inside it
-            shards = gather_packed(shard if comm_device.type == "cuda" else shard.cpu(), nbytes, dist, unpack=False)
-            torch.cuda.synchronize()
-            if shards is None:
+                last_shards[:] = to_host_async([shard], slot)
                 return plies
-            last_shards[:] = shards
-            return sum(int(sh[:16].view(torch.int64)[1]) for sh in shards)
+            if comm_device.type != "cuda":          # gloo rehearsal: host tensors all the way
+                shards = gather_packed(shard.cpu(), nbytes, dist, unpack=False)
+                if shards is not None:
+                    last_shards[:] = shards
+                return plies
+            shards = gather_packed(shard, nbytes, dist, unpack=False, to_host=False)
+            if shards is not None:
+                last_shards[:] = to_host_async(shards, 64 * slot)
+            return plies
 
         def play(en, n_games):
             en.begin(n_games)
@@ -313,8 +335,8 @@ def main():
                     t.join()
             plies = 0
             tg = time.perf_counter()
-            for en in engines:
-                plies += emit_records(en)
+            for slot, en in enumerate(engines):
+                plies += emit_records(en, slot)
             gather_s[0] += time.perf_counter() - tg
             return plies
 
@@ -342,6 +364,7 @@ def main():
         plies = 0
         for _ in range(steps):
             plies += one_step()
+        copy_stream.synchronize()                   # the last records have reached the host
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -436,7 +459,7 @@ def main():
                 "boards_per_launch": boards_per_launch,
                 "timing": ("per_launch_events" if M.get("profile_mode", 1) == 2 else
                            f"bracket_{2 * (blocks or args.blocks)}_launches (one HIP-event pair around the trunk convolutions of a forward: "
-                           "avg_launch_ms = bracket / launches, it includes the gaps between the launches"),
+                           "avg_launch_ms = bracket / launches, it includes the gaps between the launches)"),
                 "flop_per_board": flop_per_board, "tile": f"F({m_tile}x{m_tile},3x3), {tiles} tiles x {npos} positions per board",
                 "useful_cells_fraction": useful_cells, "frac_useful": tf / MFMA_F32_PEAK_TF * useful_cells,
                 "direct_conv_equivalent_tflops": tf * (9.0 * m_tile * m_tile / npos) * useful_cells, "populations": mp}
@@ -595,7 +618,7 @@ def main():
             "nn_evals_per_sec": d["nn_evals"] * world / elapsed,
             "plies_per_game": d["plies"] / max(1, d["games"]),
             "search_shape": shape,
-            "rank0": {"kernel_ms": d["kernel_ms"], "nn_ms": d["nn_ms"], "kernel_launches": d["kernel_launches"],
+            "rank0": {"kernel_ms": d["kernel_ms"], "nn_ms": d["nn_ms"] or None, "kernel_launches": d["kernel_launches"],
                       "rounds": d["rounds"], "nn_batches": d["nn_batches"], "nn_rows": d["nn_rows"],
                       "nn_fill": (d["nn_evals"] / d["nn_rows"]) if d["nn_rows"] else None, "hbm_gib": st1["hbm_bytes"] / 2**30, "model_load_and_warmup_s": t_load,
                       "max_nodes_in_arena": st1["max_nodes_in_arena"], "compactions": d["compactions"],

@@ -180,7 +180,7 @@ typedef struct sprl_stats {
     int64_t rounds, kernel_launches, nn_batches, nn_rows;   /* nn_rows = rows evaluated by the network incl. bucket padding */
     double seconds_total;      /* wall time inside run/step */
     double kernel_ms;          /* sum of tree-kernel durations (HIP events; profile=1) */
-    double nn_ms;              /* sum of network forward durations (HIP events; profile=1) */
+    double nn_ms;              /* sum of network forward durations (HIP events; with the count left on the device only in profile=2) */
     int64_t hbm_bytes;         /* device memory allocated by the engine */
     /* shader-clock cycles summed over game slots, per phase; 0 unless built with -DSPRL_PHASE_TIMERS (diagnosis) */
     int64_t cyc_total, cyc_finish, cyc_move, cyc_select, cyc_create, cyc_backup, cyc_leafio, cyc_noise,

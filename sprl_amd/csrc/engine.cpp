@@ -619,14 +619,17 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
             if (e->dev_batch && !e->forward_cb) {
                 // the evaluator reads the leaf count from the device: no host round trip between rounds; completion and
                 // errors are looked at every 8 rounds (rounds after the last game ended find nothing to do)
-                void* n0 = e->cfg.profile ? be::mark() : nullptr;
+                // (profile = 1 brackets the trunk convolutions inside the plugin; the whole-forward pair is recorded only in the
+                // per-launch mode 2: every event record is a packet in the hardware queue, and a timed run carries four per round -
+                // tree kernel and convolution bracket - instead of six)
+                void* n0 = e->cfg.profile == 2 ? be::mark() : nullptr;
                 char err[512] = { 0 };
                 if (e->torch.forward_dev(e->torch_model, P.nn_dense, &P.counters->leaf_total, max_batch_rows, e->g.planes, e->g.rows,
                                          e->g.cols, e->nn_logits, e->g.A, e->nn_value, e->stream, err, (int)sizeof(err)) != 0) {
                     e->running = false;
                     return fail(SPRL_E_MODEL, std::string("network forward failed: ") + err);
                 }
-                if (e->cfg.profile) {
+                if (n0) {
                     e->marks.push_back(n0);
                     e->marks.push_back(be::mark());
                     e->mark_kind.push_back(1);

@@ -83,18 +83,20 @@ def unpack_records(buf):
                 pdfs=pdfs, nbytes=off["total"])
 
 
-def gather_packed(shard, nbytes, dist, dst=0, unpack=True):
+def gather_packed(shard, nbytes, dist, dst=0, unpack=True, to_host=True):
     """Gather every rank's packed shard (a 1-D uint8 torch tensor on the backend's device: CUDA for "nccl" = RCCL,
     CPU for "gloo") to rank `dst`: an all_gather of the byte counts, then one gather of equal-sized padded shards.
-    Returns on `dst` the list of unpacked shards (rank order = game-shard order), or with unpack=False the raw packed shards
-    as HOST uint8 tensors (one device-to-host copy each, no decoding: what a producer that only forwards or writes the bytes
-    needs; decode later with unpack_records); None on the other ranks."""
+    Returns on `dst` the list of unpacked shards (rank order = game-shard order); with unpack=False the raw packed shards as
+    HOST uint8 tensors (one device-to-host copy each, no decoding: what a producer that only forwards or writes the bytes
+    needs; decode later with unpack_records); with unpack=False and to_host=False the shards as views of the gathered DEVICE
+    tensors - nothing leaves the device inside the call (copy them out behind a timed bracket, or on a side stream).
+    None on the other ranks."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     size = torch.tensor([int(nbytes)], dtype=torch.int64, device=shard.device)
-    sizes = [torch.zeros_like(size) for _ in range(world)]
-    dist.all_gather(sizes, size)
-    sizes = [int(s.item()) for s in sizes]
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=shard.device)
+    dist.all_gather_into_tensor(sizes_t, size)           # ONE tensor, read back with ONE host synchronisation
+    sizes = sizes_t.tolist()
     cap = max(sizes)
     if shard.numel() < cap:                              # pad to the largest shard of this step
         padded = torch.zeros(cap, dtype=torch.uint8, device=shard.device)
@@ -106,6 +108,8 @@ def gather_packed(shard, nbytes, dist, dst=0, unpack=True):
     dist.gather(shard, outs, dst=dst)
     if rank != dst:
         return None
+    if not unpack and not to_host:
+        return [t[:s] for t, s in zip(outs, sizes)]
     raw = [t[:s].cpu() for t, s in zip(outs, sizes)]
     return [unpack_records(t.numpy()) for t in raw] if unpack else raw
 

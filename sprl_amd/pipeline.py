@@ -11,6 +11,7 @@ written alongside (`write_files=True`) so the reference tooling keeps working.
 """
 import os
 import tempfile
+import time
 from dataclasses import dataclass
 from typing import Callable, Optional
 
@@ -85,18 +86,28 @@ class SelfPlayTrainLoop:
         self.next_stream += games
         return self._eng, games
 
+    def _sync(self):
+        if torch.cuda.is_available() and str(self.train_device).startswith("cuda"):
+            torch.cuda.synchronize()
+
     def self_play(self, iteration):
+        """Returns (states, dists, outcomes, stats); stats carries the stage times of this call: `t_swap` (the new model handed
+        to the engine: sprl_engine_set_model_buffer, i.e. TorchScript load + weight transforms), `t_selfplay` (the games) and
+        `t_ingest` (records expanded on the device into the sample tensors)."""
         eng, games = self._engine(iteration)
+        t0 = time.perf_counter()
         if self.traced is None:
             eng.set_model("random")                 # GridWorker.hpp:125-127
         elif self.forward_factory is not None:
             eng.set_forward(self.forward_factory(self.net))
         else:
             eng.set_model_bytes(self.traced)        # hot swap through memory: no file, no polling
+        t1 = time.perf_counter()
         eng.begin(games)
         done = 0
         while done < games:
             done, _ = eng.step(64)
+        t2 = time.perf_counter()
         _, samples, _ = eng.records_info()
         rows, cols, actions, hist = GAME_SHAPES[self.cfg.game]
         # the engine's "device" is the GPU for the product library, host memory for the CPU emulator build used in tests
@@ -114,14 +125,27 @@ class SelfPlayTrainLoop:
             rec.close()
         else:
             eng.finish()
-        stats = dict(eng.stats(), games=games)      # (a kept engine's counters run on across iterations)
+        self._sync()
+        t3 = time.perf_counter()
+        stats = dict(eng.stats(), games=games, t_swap=t1 - t0, t_selfplay=t2 - t1, t_ingest=t3 - t2)     # (a kept engine's counters run on across iterations)
         return states, dists, outcomes, stats
 
     def step(self, iteration):
+        """One iteration of the reference controller + worker fleet (scripts/othello_controller.py:243-343): self-play with the
+        current network, ingest, train, export.  The record carries the wall time of every stage:
+        t_swap / t_selfplay / t_ingest (see self_play), t_window (replay window concatenated), t_train (train_network: epochs x
+        optimiser steps + validation), t_export (best weights traced to an in-memory TorchScript archive), t_total."""
+        t_begin = time.perf_counter()
         states, dists, outcomes, stats = self.self_play(iteration)
+        t0 = time.perf_counter()
         self.window.add(iteration, states, dists, outcomes)
         lr = T.learning_rate_for(self.tcfg, iteration)
-        best, hist = T.train_network(self.net, lr, self.window.training_tensors(iteration), self.tcfg)
+        tensors = self.window.training_tensors(iteration)
+        self._sync()
+        t1 = time.perf_counter()
+        best, hist = T.train_network(self.net, lr, tensors, self.tcfg)
+        self._sync()
+        t2 = time.perf_counter()
         # the best-validation weights traced into a TorchScript archive IN MEMORY (what othello_controller.py:237-239 writes to
         # traced_<run>_iteration_<i>.pt); the file itself only exists with write_files=True, for the reference tooling
         self.traced = T.export_best_bytes(self.net, best, self.cfg.game) if self.forward_factory is None else True
@@ -134,11 +158,20 @@ class SelfPlayTrainLoop:
                 with open(self.model_path + ".tmp", "wb") as f:
                     f.write(self.traced)
                 os.replace(self.model_path + ".tmp", self.model_path)
+        t3 = time.perf_counter()
+        n_window = int(tensors[0].shape[0])
+        epochs = len(hist["epochs"])
+        steps_per_epoch = (int((1.0 - self.tcfg.val_fraction) * n_window) + self.tcfg.batch_size - 1) // self.tcfg.batch_size
         rec = dict(iteration=iteration, samples=int(states.shape[0]), games=stats["games"], lr=lr,
-                   best_epoch=hist["best_epoch"], best_val=hist["best_val"], model=self.model_path)
+                   best_epoch=hist["best_epoch"], best_val=hist["best_val"], model=self.model_path,
+                   window_samples=n_window, epochs=epochs, optimiser_steps=epochs * steps_per_epoch,
+                   t_swap=stats["t_swap"], t_selfplay=stats["t_selfplay"], t_ingest=stats["t_ingest"], t_window=t1 - t0,
+                   t_train=t2 - t1, t_export=t3 - t2, t_total=t3 - t_begin)
         self.history.append(rec)
         self.log(f"iteration {iteration}: {rec['games']} games, {rec['samples']} samples, best val {rec['best_val']:.4f} "
-                 f"@ epoch {rec['best_epoch']}")
+                 f"@ epoch {rec['best_epoch']}; swap {rec['t_swap']:.2f} s, self-play {rec['t_selfplay']:.2f} s, ingest "
+                 f"{rec['t_ingest']:.3f} s, window {rec['t_window']:.3f} s ({n_window} samples), train {rec['t_train']:.2f} s "
+                 f"({epochs} epochs x {steps_per_epoch} steps), export {rec['t_export']:.2f} s, total {rec['t_total']:.2f} s")
         return rec
 
     def run(self):

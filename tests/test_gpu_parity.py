@@ -376,6 +376,12 @@ def test_in_process_selfplay_training_loop(lib, tmp_path):
     # the model went back to the engine through memory (sprl_engine_set_model_buffer) and was used: evaluations happened
     assert hist[1]["samples"] > 0 and isinstance(loop.traced, bytes)
     assert not list(tmp_path.rglob("*.pt")) and not list(tmp_path.rglob("*.npy"))     # nothing went through the file system
+    # every iteration carries its stage times (whole-iteration turnaround; the Othello numbers come from
+    # tools/iteration_turnaround.py): the stages add up to the total, and the swap of iteration i+1 is the model of iteration i
+    for h in hist:
+        parts = h["t_swap"] + h["t_selfplay"] + h["t_ingest"] + h["t_window"] + h["t_train"] + h["t_export"]
+        assert h["t_selfplay"] > 0 and h["t_train"] > 0 and h["epochs"] == 3 and h["optimiser_steps"] >= 3
+        assert parts <= h["t_total"] * 1.001 and parts >= 0.9 * h["t_total"], h
 
 
 # ---- match play (Evaluate.cpp) on the device ----
