@@ -119,6 +119,21 @@ struct HeadArgs {
     int A, HID;
     unsigned magic_a, magic_h;       // ceil(2^20 / A), ceil(2^20 / HID): t / A == (t * magic_a) >> 20 for t < 512
 };
+// The stem (3 input planes -> 64 channels, 3x3, folded BN, ReLU; grid_networks.py:36-38,56) fused into the FIRST trunk convolution
+// (STEM = 1, round 4): the workgroup computes the stem output of its four boards in its prologue - one wave per board, out[64 ch]
+// [64 cells] = W[64][27] x patches[27][64] on v_mfma_f32_16x16x4_f32 exactly as cnn_epilogue.hip: stem_mfma_kernel does - stores it
+// to x0 (layout W; the next convolution's residual input) and then runs the convolution on it, reading it back through L2 (the
+// lines were written by this CU a moment ago: `s_waitcnt vmcnt(0)` + barrier, same XCD).  The accumulators are not live yet, so
+// the 28 weight registers and 32 scale / shift registers cost nothing; the plane images sit in the V buffer, which is free until
+// the first V is built.  One launch and one pass of 16 KB per board through HBM less per forward (the stem kernel wrote x0,
+// this convolution read it back from HBM).
+struct StemArgs {
+    const float* planes;    // [batch][3][H][W] input planes
+    const float* w;         // [64][27] stem convolution weights
+    const float *scale, *shift;   // [64] folded BatchNorm of the stem
+    float* x0;              // = the convolution's input x: written here, [batch][4096] in layout W
+};
+
 // HEADS = 2 task split: the policy contraction (<= 128 long) in four parts, the hidden layer's (<= 64) in two; a task is one output
 // column x one part x the four boards of the workgroup, at most 32 weights long
 constexpr int FC_MAXA = 96, FC_LP = 32;
@@ -139,11 +154,12 @@ constexpr int IN_BUF2 = 8 * CS2;
 constexpr int V_G2 = 36 * 64;            // V of one group: [p][c_sub][16 tiles]
 constexpr int LDS_FLOATS2 = 2 * IN_BUF2 + 4 * V_G2;      // 65.6 KB
 
-template <int H, int W, int HEADS = 0, int RES = 1>
-__global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __restrict__ x, const float* __restrict__ u,
+template <int H, int W, int HEADS = 0, int RES = 1, int STEM = 0>
+__global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, const float* __restrict__ u,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ res, float* __restrict__ y, int batch,
-                                                               int relu, const unsigned* __restrict__ batch_dev, HeadArgs ha) {
+                                                               int relu, const unsigned* __restrict__ batch_dev, HeadArgs ha,
+                                                               StemArgs sa) {
     // batch_dev != null: the number of boards is on the device (the engine's leaf count of this round), `batch` is the
     // capacity the grid was sized for; workgroups past the real count leave at once
     if (batch_dev) {
@@ -315,7 +331,75 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* __re
         if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G2, 2 * c + 2, -1, std::false_type{});
     };
 
-    {   // the first two chunks are requested together: one HBM round trip before the first V can be built, not two
+    if constexpr (STEM) {
+        // ---- the stem of this workgroup's four boards: wave w = board n0 + w (see StemArgs) ----
+        // The filter quads of K step 0 are requested first and arrive under the stem; channels 0..15 of the stem output ARE the
+        // activation chunks 0 and 1 (groups 0..3), so they go straight into the two LDS images as well - the K loop's first V is
+        // built from them without a trip to memory; the chunks from 2 on are read back from x0 (L2) behind the drain + barrier.
+#pragma unroll
+        for (int q4 = 0; q4 < 9; ++q4) aload(0, q4);
+        __syncthreads();                               // zero fill done (the stem writes the interiors of both images)
+        constexpr int HW = H * W;
+        float* const im = v_buf + wave * 300;          // zero-bordered 10x10 images of the board's three planes
+        for (int i = lane; i < 300; i += 64) im[i] = 0.0f;
+        const int n = n0 + wave;
+        const int qs = lane >> 4, l16 = lane & 15;     // K slot of this lane inside a step, column of the 16x16 tile
+        const int stile = l16 >> 2, sj = l16 & 3;
+        if (n < batch) {
+            for (int e = lane; e < 3 * HW; e += 64) {
+                const int pl = e / HW, cell = e % HW;
+                im[pl * 100 + (cell / W + 1) * 10 + cell % W + 1] = sa.planes[(size_t)n * 3 * HW + e];
+            }
+        }
+        float wf[4][7];                                // A fragments: lane -> (channel 16 kb + l16, K index 4 s + qs)
+        int qoff[7];                                   // B fragments: offset of tap q = plane * 100 + dy * 10 + dx
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7) {
+            const int q = 4 * s7 + qs;
+            qoff[s7] = q < 27 ? (q / 9) * 100 + ((q % 9) / 3) * 10 + (q % 3) : -1;
+#pragma unroll
+            for (int kb4 = 0; kb4 < 4; ++kb4) wf[kb4][s7] = q < 27 ? sa.w[(16 * kb4 + l16) * 27 + q] : 0.0f;
+        }
+        float ssc[4][4], ssh[4][4];                    // channel 16 kb + 4 qs + r  (row of the accumulator tile)
+#pragma unroll
+        for (int kb4 = 0; kb4 < 4; ++kb4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ssc[kb4][r] = sa.scale[16 * kb4 + 4 * qs + r];
+                ssh[kb4][r] = sa.shift[16 * kb4 + 4 * qs + r];
+            }
+        const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc((void*)sa.x0, 0, act_bytes, 0x00020000);
+        const int cell0 = (4 * (stile >> 1)) * 10 + 4 * (stile & 1) + sj;      // + cb * 10 for row-in-tile cb
+        const int scol = 4 * (stile & 1) + sj;
+        const int svoff = (n * 4096 + qs * 16 + l16) * 4;       // the per-lane offset carries the board: boards >= batch are not stored
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f4 sacc[4];
+#pragma unroll
+            for (int s7 = 0; s7 < 7; ++s7) {
+                const float bv = qoff[s7] >= 0 ? im[qoff[s7] + cell0 + cb * 10] : 0.0f;
+#pragma unroll
+                for (int kb4 = 0; kb4 < 4; ++kb4)
+                    sacc[kb4] = s7 == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb4][s7], bv, (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb4][s7], bv, sacc[kb4], 0, 0, 0);
+            }
+            const bool on_board = 4 * (stile >> 1) + cb < H && scol < W;
+#pragma unroll
+            for (int kb4 = 0; kb4 < 4; ++kb4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = sacc[kb4][r] * ssc[kb4][r] + ssh[kb4][r];      // (two roundings, as the stand-alone stem kernel)
+                    const float o = on_board ? (v > 0.0f ? v : 0.0f) : 0.0f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rx0, svoff, ((4 * kb4 + r) * 256 + cb * 64) * 4, 0);
+                    if (kb4 == 0)                      // channel 4 qs + r = group r, slot qs: chunk r >> 1, group r & 1 of the chunk
+                        in_buf[(r >> 1) * IN_BUF2 + ((r & 1) * 4 + qs) * CS2 + board_off(wave) + (4 * (stile >> 1) + cb + 1) * RS + 4 * (stile & 1) + sj + 1] = o;
+                }
+        }
+        // every wave's stores have reached L2 before any wave of the workgroup reads x0 back (the loads below miss this CU's L1:
+        // nothing of these boards has been loaded in this launch)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {   // the first two chunks are requested together: one HBM round trip before the first V can be built, not two
         // (chunk 2 requested here as well, behind the filter quads of K step 0 and into registers of its own, was measured at the
         // end of round 3: 203.0 -> 209.0 us; earlier in the round in front of them: 1-2 % slower too)
         f4 first[2];
@@ -1041,19 +1125,25 @@ extern "C" int sprl_wino_weight_layout(void) { return 2; }
 namespace {
 template <int HEADS>
 int launch_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y, int batch,
-                  int H, int W, int relu, const unsigned* batch_dev, const HeadArgs& ha_in, void* stream) {
+                  int H, int W, int relu, const unsigned* batch_dev, const HeadArgs& ha_in, void* stream, const StemArgs* stem = nullptr) {
     if (batch <= 0) return 0;
     if ((long long)batch * 16384LL >= 0xFFFFFFFFLL) return -1;      // byte offsets of the buffer descriptors are 32 bits
     const HeadArgs& ha = ha_in;
+    const StemArgs sa = stem ? *stem : StemArgs{};
     const dim3 grid((unsigned)((batch + NIMG2 - 1) / NIMG2)), block(NTHR2);
     hipStream_t st = (hipStream_t)stream;
     // RES = 0: the first convolution of a residual block has no residual input - no loads, no adds for it
 #define SPRL_LAUNCH_CONV(HH, WW)                                                                                                        \
     do {                                                                                                                                \
-        if (HEADS || res)                                                                                                               \
-            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, HEADS, 1>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha); \
-        else                                                                                                                            \
-            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha);     \
+        if constexpr (HEADS != 0) {                                                                                                     \
+            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, HEADS, 1, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha, sa); \
+        } else if (stem) {                                                                                                              \
+            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 0, 1>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha, sa);     \
+        } else if (res) {                                                                                                               \
+            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 1, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha, sa);     \
+        } else {                                                                                                                        \
+            hipLaunchKernelGGL((wino_conv64_kernel<HH, WW, 0, 0, 0>), grid, block, 0, st, x, u, scale, shift, res, y, batch, relu, batch_dev, ha, sa);     \
+        }                                                                                                                               \
     } while (0)
     if (H == 8 && W == 8) SPRL_LAUNCH_CONV(8, 8);
     else if (H == 6 && W == 7) SPRL_LAUNCH_CONV(6, 7);
@@ -1070,6 +1160,15 @@ int launch_conv64(const float* x, const float* u, const float* scale, const floa
 extern "C" int sprl_wino_conv64_dev(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                     float* y, int batch, int H, int W, int relu, const unsigned* batch_dev, void* stream) {
     return launch_conv64<0>(x, u, scale, shift, res, y, batch, H, W, relu, batch_dev, HeadArgs{}, stream);
+}
+// The FIRST trunk convolution with the stem in its prologue (3 input planes; no residual input): planes [batch][3][H][W] ->
+// x0 = ReLU(BN(conv3x3(planes))) (written, layout W: the next convolution's residual) -> y = ReLU(BN(conv3x3(x0))).
+// stem_w: [64][27]; y must not alias x0.  Replaces sprl_stem_conv3x3_w + sprl_wino_conv64_dev (one launch less per forward).
+extern "C" int sprl_wino_conv64_stem(const float* planes, const float* stem_w, const float* stem_scale, const float* stem_shift, float* x0,
+                                     const float* u, const float* scale, const float* shift, float* y, int batch, int H, int W,
+                                     const unsigned* batch_dev, void* stream) {
+    StemArgs sa{ planes, stem_w, stem_scale, stem_shift, x0 };
+    return launch_conv64<0>(x0, u, scale, shift, nullptr, y, batch, H, W, 1, batch_dev, HeadArgs{}, stream, &sa);
 }
 extern "C" int sprl_wino_conv64(const float* x, const float* u, const float* scale, const float* shift, const float* res,
                                 float* y, int batch, int H, int W, int relu, void* stream) {

@@ -64,6 +64,9 @@ extern "C" int sprl_wino_conv64_heads_fc(const float* x, const float* u, const f
                                          const float* pfc_w, const float* pfc_b, const float* vfc1_w, const float* vfc1_b,
                                          const float* vfc2_w, const float* vfc2_b, float* logits, float* value, int A, int HID,
                                          void* stream);
+extern "C" int sprl_wino_conv64_stem(const float* planes, const float* stem_w, const float* stem_scale, const float* stem_shift, float* x0,
+                                     const float* u, const float* scale, const float* shift, float* y, int batch, int H, int W,
+                                     const unsigned* batch_dev, void* stream);
 extern "C" int sprl_wino_conv64_t_occ(const float* x, const float* u, const float* scale, const float* shift, const float* res, float* y,
                                       int batch, int H, int W, int relu, int tile, int occ, const unsigned* batch_dev, void* stream);
 extern "C" int sprl_stem_conv3x3_w_form(const float* planes, const float* w, const float* scale, const float* shift, float* y,
@@ -82,7 +85,7 @@ namespace {
 // tests of the fallback paths).  They are read ONCE, when a model is loaded - never per forward or per launch - kept in the model
 // and reported by sprl_torch_path_info, so a timed run can refuse to start on anything but the default path (bench.py does).
 struct PathSwitches {
-    bool no_native = false, no_rewrite = false, no_winograd = false, no_conv_tail = false, no_conv_fc = false, no_nchw_native = false,
+    bool no_native = false, no_rewrite = false, no_winograd = false, no_conv_tail = false, no_conv_fc = false, no_conv_stem = false, no_nchw_native = false,
          no_nchw_stem = false, no_winograd_nchw = false, no_fused_tail = false, stem_valu = false, tail_no_mfma = false;
     int nchw_tile = 0, f3_occ = 0;
     std::string active;                  // the names that were set, space separated ("" = the default path)
@@ -105,6 +108,7 @@ struct PathSwitches {
         flag("SPRL_TORCH_NO_WINOGRAD", sw.no_winograd);
         flag("SPRL_TORCH_NO_CONV_TAIL", sw.no_conv_tail);
         flag("SPRL_TORCH_NO_CONV_FC", sw.no_conv_fc);
+        flag("SPRL_TORCH_NO_CONV_STEM", sw.no_conv_stem);
         flag("SPRL_TORCH_NO_NCHW_NATIVE", sw.no_nchw_native);
         flag("SPRL_TORCH_NO_NCHW_STEM", sw.no_nchw_stem);
         flag("SPRL_TORCH_NO_WINOGRAD_NCHW", sw.no_winograd_nchw);
@@ -207,6 +211,7 @@ struct Model {
     at::Tensor act[3], maps;     // activation buffers of the hand-written path, kept across calls (no allocator traffic, any stream)
     at::Tensor nact[3], npmaps;  // the same for boards wider than 8 (NCHW with the slack sprl_wino_conv64_nchw needs; policy head maps)
     int64_t nact_floats = 0, nact_pmaps = 0;     // allocated sizes: activations (floats per buffer), policy maps (floats)
+    int last_stem = 0;           // 1: the last 8x8 forward ran the stem inside the first trunk convolution (no stem launch)
     int last_tail = 0;           // what the last 8x8 forward ended in: 2 = conv + heads + FC in one launch, 1 = heads fused + FC kernel, 0 = separate tail
 };
 
@@ -340,7 +345,11 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
         (void)hipDeviceSynchronize();            // the buffers may be used on another stream than the one that allocated them
     }
     at::Tensor x = mdl->act[0], y = mdl->act[1], z = mdl->act[2];
-    if (sprl_stem_conv3x3_w_form(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
+    // 3 input planes: the stem runs in the prologue of the first trunk convolution (round 4) - no stem launch
+    const bool stem_in_conv = P == 3 && !mdl->sw.stem_valu && !mdl->sw.no_conv_stem && in.is_contiguous();
+    mdl->last_stem = stem_in_conv ? 1 : 0;
+    if (!stem_in_conv &&
+        sprl_stem_conv3x3_w_form(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
                                  n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), B, P, H, W, mdl->sw.stem_valu ? 1 : 0, batch_dev, stream) != 0)
         return false;
     if (prof) prof->open((hipStream_t)stream);       // one event pair around all the trunk convolutions of this forward
@@ -363,7 +372,19 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                            !mdl->sw.no_conv_tail;
     for (size_t bi = 0; bi < n.blocks.size(); ++bi) {
         const auto& b = n.blocks[bi];
-        if (!conv(x, b.u1, b.s1, b.t1, nullptr, y)) return false;
+        if (bi == 0 && stem_in_conv) {
+            const int rc = sprl_wino_conv64_stem(in.data_ptr<float>(), n.stem_w.data_ptr<float>(), n.stem_scale.data_ptr<float>(),
+                                                 n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), b.u1.data_ptr<float>(), b.s1.data_ptr<float>(),
+                                                 b.t1.data_ptr<float>(), y.data_ptr<float>(), B, H, W, batch_dev, stream);
+            if (prof) {
+                prof->note(B);
+                if (prof->per_launch) {
+                    prof->close((hipStream_t)stream);
+                    prof->open((hipStream_t)stream);
+                }
+            }
+            if (rc != 0) return false;
+        } else if (!conv(x, b.u1, b.s1, b.t1, nullptr, y)) return false;
         if (fuse_last && bi + 1 == n.blocks.size()) {
             // last convolution + both head convolutions + the FC layers in ONE kernel: the forward ends in this launch (round 4)
             if (!mdl->sw.no_conv_fc) {
@@ -781,13 +802,16 @@ int sprl_torch_forward_dev(void* handle, const float* planes, const unsigned* ba
 
 void sprl_torch_free(void* handle) { delete static_cast<Model*>(handle); }
 
-// What the model's forward resolves to: "kind=<0|1|2> tail=<2|1|0> lab=[<switches that were set when it was loaded>]".  kind as
-// sprl_torch_is_native; tail (boards up to 8x8, after the first forward): 2 = last convolution + heads + FC layers in one launch,
-// 1 = heads fused into the last convolution + FC kernel, 0 = separate tail kernel.  An empty lab list = the default path.
+// What the model's forward resolves to: "kind=<0|1|2> stem=<1|0> tail=<2|1|0> lab=[<switches that were set when it was loaded>]".
+// kind as sprl_torch_is_native; boards up to 8x8, after the first forward: stem 1 = the stem runs inside the first trunk
+// convolution (3 input planes), 0 = its own launch; tail 2 = last convolution + heads + FC layers in one launch, 1 = heads fused
+// into the last convolution + FC kernel, 0 = separate tail kernel.  An empty lab list = the default path.  The default 8x8 forward
+// of the 2-block network is FOUR launches: conv(stem) - conv - conv - conv(heads, FC).
 int sprl_torch_path_info(void* handle, char* buf, int len) {
     if (!handle || !buf || len < 1) return -1;
     const Model* m = static_cast<Model*>(handle);
-    snprintf(buf, (size_t)len, "kind=%d tail=%d lab=[%s]", m->native.ok ? (m->native.wino ? 2 : 1) : 0, m->last_tail, m->sw.active.c_str());
+    snprintf(buf, (size_t)len, "kind=%d stem=%d tail=%d lab=[%s]", m->native.ok ? (m->native.wino ? 2 : 1) : 0, m->last_stem, m->last_tail,
+             m->sw.active.c_str());
     return 0;
 }
 

@@ -31,6 +31,11 @@ class TrainerConfig:
     num_past_iters_to_train: int = 10      # :47
     linear_weighting: bool = True          # :45
     val_fraction: float = 0.1              # :135-136
+    use_graph: bool = True                 # MI355X: replay the optimiser step (gather, forward, losses, backward, AdamW) from ONE
+                                           # captured HIP graph per full-size batch instead of ~100 kernel launches: the eager step
+                                           # is bound by its launches (round 4: 6.5 -> 2.4 ms per step incl. validation on a GPU box
+                                           # with slow host cores, profiles/r04h_trainer_*.txt).  Single GPU, CUDA device and the
+                                           # random split only; otherwise, or when the capture fails, the eager loop runs.
 
 
 def weighted_losses(logits, value, target_pdf, target_value, weight):
@@ -96,6 +101,60 @@ def _evaluate(net, tensors, batches):
     return acc
 
 
+class _GraphStep:
+    """One optimiser step - gather the batch from the HBM-resident window, forward, the two weighted losses, backward, AdamW, loss
+    sums - captured once as a HIP graph (torch.cuda.CUDAGraph) and replayed per batch: the step of the 2 x 64 network is a chain
+    of ~100 short kernels and the stock eager loop is bound by their launches, not by their execution (profiles/r04*_trainer_*).
+    The only per-batch input is the index vector, copied into a static buffer.  Capture needs a few warm-up steps (library
+    kernel selection must not happen inside a capture); they are real optimiser steps, so parameters, BatchNorm statistics and the
+    AdamW state are put back IN PLACE afterwards - the captured graph holds their addresses."""
+
+    def __init__(self, net, opt, tensors, batch_size, warm_idx):
+        s, d, o, t = tensors
+        dev = s.device
+        self.idx = warm_idx.clone()
+        self.acc = torch.zeros(2, device=dev, dtype=torch.float64)
+        saved = {k: v.clone() for k, v in net.state_dict().items()}
+
+        def body():
+            i = self.idx
+            lo, va = net(s[i])
+            pl, vl = weighted_losses(lo, va, d[i], o[i], t[i])
+            opt.zero_grad(set_to_none=True)
+            (pl + vl).backward()
+            opt.step()
+            self.acc[0] += pl.detach().double()
+            self.acc[1] += vl.detach().double()
+
+        net.train()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+        with torch.no_grad():                          # undo the warm-up steps, in place
+            for k, v in net.state_dict().items():
+                v.copy_(saved[k])
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        self.acc.zero_()
+
+    def __call__(self, batch_idx):
+        self.idx.copy_(batch_idx)
+        self.graph.replay()
+
+    def drain(self, tacc):
+        """once per epoch: the loss sums the replays have accumulated in the graph's static buffer"""
+        tacc += self.acc
+        self.acc.zero_()
+
+
 def _dist():
     import torch.distributed as dist
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
@@ -138,7 +197,20 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
     if dist is not None:
         from torch.nn.parallel import DistributedDataParallel
         model = DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None)
-    opt = torch.optim.AdamW(model.parameters(), lr=learning_rate)               # :144
+    graph_step = None
+    opt = None
+    if cfg.use_graph and device.type == "cuda" and dist is None and index_plan is None and train_idx.numel() >= cfg.batch_size:
+        before = copy.deepcopy(net.state_dict())
+        try:
+            opt = torch.optim.AdamW(model.parameters(), lr=learning_rate, capturable=True)
+            graph_step = _GraphStep(net, opt, tensors, cfg.batch_size, train_idx[:cfg.batch_size])
+        except Exception as exc:                                                 # (an optimisation only: same arithmetic either way)
+            if log:
+                log(f"HIP graph capture of the optimiser step failed ({exc}); eager steps")
+            net.load_state_dict(before)
+            graph_step, opt = None, None
+    if opt is None:
+        opt = torch.optim.AdamW(model.parameters(), lr=learning_rate)           # :144
     best_val, best_epoch, best_state = float("inf"), 0, copy.deepcopy(net.state_dict())
     history = []
     for group in range(cfg.max_groups):
@@ -158,6 +230,10 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
             tacc = torch.zeros(2, device=device, dtype=torch.float64)
             nb = 0
             for b in train_batches:
+                if graph_step is not None and b.numel() == cfg.batch_size:
+                    graph_step(b)
+                    nb += 1
+                    continue
                 lo, va = model(s[b])
                 pl, vl = weighted_losses(lo, va, d[b], o[b], t[b])
                 opt.zero_grad(set_to_none=True)
@@ -166,6 +242,8 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                 tacc[0] += pl.detach().double()
                 tacc[1] += vl.detach().double()
                 nb += 1
+            if graph_step is not None:
+                graph_step.drain(tacc)
             model.eval()
             if dist is not None:                                                 # BatchNorm running statistics: average the ranks'
                 for buf in net.buffers():                                        # (the parameters are already identical)

@@ -248,7 +248,7 @@ def test_handwritten_cnn_against_reference_golden_baseline_shape(lib, golden, tm
         h = plug.sprl_torch_load(path.encode(), 0, err, 512)
         assert h and plug.sprl_torch_is_native(h) == 2, err.value
         lo, va = _plugin_forward(plug, h, x, 65)
-        assert _path_info(plug, h) == "kind=2 tail=2 lab=[]"         # the forward ended in the last convolution's launch, no lab switch
+        assert _path_info(plug, h) == "kind=2 stem=1 tail=2 lab=[]"  # four launches: stem inside conv 1, heads + FC inside conv 4; no lab switch
         plug.sprl_torch_free(h)
         e_ref = max(np.abs(lo - g[f"logits{gi}"]).max(), np.abs(va - g[f"value{gi}"].reshape(-1)).max())
         e_f64 = max(np.abs(lo - g[f"logits_f64_{gi}"]).max(), np.abs(va - g[f"value_f64_{gi}"].reshape(-1)).max())
@@ -283,6 +283,7 @@ def test_native_cnn_path_matches_torchscript(lib, game, tail, tmp_path, monkeypa
     import torch
     if tail == 1:
         monkeypatch.setenv("SPRL_TORCH_NO_CONV_FC", "1")
+        monkeypatch.setenv("SPRL_TORCH_NO_CONV_STEM", "1")
     from sprl_amd.network import GAME_SHAPES, make_network, trace_to_file
     model = trace_to_file(make_network(game, 2, 64, seed=1), str(tmp_path / f"traced_{game}.pt"), game)
     rows, cols, actions, hist = GAME_SHAPES[game]
@@ -309,7 +310,9 @@ def test_native_cnn_path_matches_torchscript(lib, game, tail, tmp_path, monkeypa
             rl, rv = ref(x)
         np.testing.assert_allclose(lo.cpu().numpy(), rl.cpu().numpy(), atol=CNN_ATOL, rtol=0)
         np.testing.assert_allclose(va.cpu().numpy(), rv.cpu().numpy().reshape(-1), atol=CNN_ATOL, rtol=0)
-    assert _path_info(plug, h) == f"kind=2 tail={tail} lab=[{'SPRL_TORCH_NO_CONV_FC' if tail == 1 else ''}]"
+    stem = 1 if (planes == 3 and tail == 2) else 0          # (go7: 17 planes keep the stem launch; the tail = 1 leg also switches the stem fold off)
+    assert _path_info(plug, h) == f"kind=2 stem={stem} tail={tail} lab=[{'SPRL_TORCH_NO_CONV_FC SPRL_TORCH_NO_CONV_STEM' if tail == 1 else ''}]"
+    monkeypatch.delenv("SPRL_TORCH_NO_CONV_STEM", raising=False)
     monkeypatch.delenv("SPRL_TORCH_NO_CONV_FC", raising=False)
     h2 = plug.sprl_torch_load(model.encode(), 0, err, 512)           # the switch was read at load: a model loaded now has none
     assert _path_info(plug, h2).endswith("lab=[]")

@@ -3,6 +3,7 @@ one GPU, over a fixed number of search rounds in the middle of the games (a 19x1
 traversals/s, expansions/s, moves/s, for the in-kernel uniform evaluator and for a traced CNN through the LibTorch path.
 Secondary measurement; the headline bench is bench.py."""
 import argparse
+import json
 import os
 import sys
 import tempfile
@@ -59,6 +60,7 @@ def main():
                 print(f"{game}: {games} games, {name} [{info}]: {rounds} rounds in {dt:.2f} s -> "
                       f"{d['traversals'] / dt / 1e6:.2f} M traversals/s, {d['expansions'] / dt / 1e6:.2f} M expansions/s, "
                       f"{d['traversals'] / dt / 1600:.0f} moves/s, {d['nn_evals'] / dt / 1e6:.2f} M evals/s", flush=True)
+                print("JSON " + json.dumps(dict(game=game, games=games, evaluator=name, rounds=rounds, seconds=dt, **d)), flush=True)
 
 
 if __name__ == "__main__":

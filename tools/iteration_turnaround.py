@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--init-traversals", type=int, default=800, help="the reference's iteration 0 searches 131072 traversals with the "
                     "uniform evaluator (OTHWorker.cpp:21); the steady-state budget here keeps the run short")
     ap.add_argument("--max-groups", type=int, default=10)
+    ap.add_argument("--graph", action="store_true", help="TrainerConfig.use_graph: the optimiser step replayed from a captured HIP graph")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "iteration_turnaround.txt"))
     a = ap.parse_args()
     from sprl_amd import trainer as T
     from sprl_amd.pipeline import LoopConfig, SelfPlayTrainLoop
     cfg = LoopConfig(game="othello", num_iters=a.iters, init_games=a.games, init_traversals=a.init_traversals, init_max_batch=8,
                      init_max_queue=4, games=a.games, traversals=a.traversals, concurrent_games=a.games, num_blocks=2, num_channels=64)
-    tcfg = T.TrainerConfig(max_groups=a.max_groups)
+    tcfg = T.TrainerConfig(max_groups=a.max_groups, use_graph=a.graph)
     lines = []
     loop = SelfPlayTrainLoop(cfg, tcfg, log=lambda s: (print(s, flush=True), lines.append(s)))
     hist = loop.run()

@@ -10,6 +10,6 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 rm -rf /tmp/kt_$TAG
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o k -- \
-    python3 $REPO/bench.py --no-cpu-baseline --no-alone-pass > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+    python3 $REPO/bench.py --no-cpu-baseline --no-secondary --no-alone-pass > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 cp "$(find /tmp/kt_$TAG -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_bench_kernel_stats.csv
 echo "kernel stats done"

@@ -10,7 +10,7 @@ run_pass() {
   local name=$1; shift
   rm -rf /tmp/pmc_$name
   timeout -k 10 500 rocprofv3 --pmc "$@" --kernel-include-regex step_kernel --output-format csv -d /tmp/pmc_$name -o p -- \
-      python3 $REPO/bench.py --no-cpu-baseline --no-profile --populations 1 $EXTRA > $REPO/gpurun_out/${TAG}_pmc_${name}.log 2>&1 || return 1
+      python3 $REPO/bench.py --no-cpu-baseline --no-secondary --no-profile --populations 1 $EXTRA > $REPO/gpurun_out/${TAG}_pmc_${name}.log 2>&1 || return 1
   local f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   python3 $REPO/tools/pmc_summary.py "$f" step_kernel > $REPO/gpurun_out/${TAG}_pmc_${name}_summary.csv
   echo "pass $name done: $(wc -l < $REPO/gpurun_out/${TAG}_pmc_${name}_summary.csv) lines"

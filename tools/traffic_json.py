@@ -43,7 +43,9 @@ for k in fetch:
     _, w_kb = write[k]["WRITE_SIZE"]
     hbm = (2.0 * f_kb + w_kb) * 1024.0
     # per board and launch: 16 KB of activations in, + 16 KB residual (RES), + 16 KB out (or 768 B of head maps with HEADS)
-    algo = boards * (16384 + (16384 if res else 0) + (768 if heads else 16384))
+    # (HEADS = 1: 768 B of head maps; HEADS = 2, round 4: the forward ends in the launch - 65 logits + 1 value = 264 B - and the
+    # 50 KB of FC weights come from L2)
+    algo = boards * (16384 + (16384 if res else 0) + (264 if heads == 2 else 768 if heads else 16384))
     per[name] = {"FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb, "launches": n, "hbm_bytes_per_launch": hbm, "algorithmic": algo}
     tot_b += hbm * n
     tot_a += algo * n
@@ -61,7 +63,7 @@ with open(os.path.join(src, f"{tag}_bench_kernel_stats.csv"), newline="") as f:
 conv_calls = sum(c for k, (c, a) in kt.items() if "wino_conv64_kernel<8, 8" in k)
 conv_avg = sum(c * a for k, (c, a) in kt.items() if "wino_conv64_kernel<8, 8" in k) / max(1, conv_calls) / 1e6
 conv = {"kernel": "wino_conv64_kernel<8,8,HEADS,RES> (cnn_wino.hip; per forward of the 2-block net: RES = 0, RES = 1, RES = 0, and the last one with "
-                  "the head convolutions fused, HEADS = 1)",
+                  "the head convolutions and the FC layers fused, HEADS = 2)",
         "command": f"python bench.py --populations 1 (4096 games, 800 it/move, CNN), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes "
                    f"(tools/profile_round.sh {tag} wino_conv64_kernel; tools/traffic_json.py {tag})",
         "per_variant": per, "fetch_correction": 2.0, "write_correction": 1.0,
