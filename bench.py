@@ -378,6 +378,14 @@ def main():
         d = {k: st1[k] - st0[k] for k in st1 if isinstance(st1[k], (int, float)) and k not in ("max_nodes_in_arena", "hbm_bytes")}
         verified = verify_last_shards()
         info = engines[0].evaluator_info() if model_path else args.model
+        kinds = None
+        if model_path and profile_mode == 2 and not args.no_profile:
+            kinds = {}
+            for en in engines:
+                for k, (ms, n) in en.conv_kinds().items():
+                    a = kinds.setdefault(k, [0.0, 0])
+                    a[0] += ms
+                    a[1] += n
         if model_path and not args.allow_lab:
             # the number is only valid on the default hand-written path: the evaluator string carries the plugin's resolved path and
             # every lab switch (SPRL_*) that was set when the model was loaded / the engine created
@@ -390,7 +398,7 @@ def main():
             en.close()
         return dict(pops=pops, steps=steps, elapsed=elapsed, d=d, st1=st1, tree_busy=tree_busy, tree_sum=tree_sum,
                     conv_busy=conv_busy, conv_sum=conv_sum, t_load=t_load, gather_s=gather_s[0], shard_bytes=shard_bytes[0],
-                    evaluator=info, verified=verified, profile_mode=profile_mode)
+                    evaluator=info, verified=verified, profile_mode=profile_mode, kinds=kinds)
 
     def rooflines(M, G=G, game=args.game, blocks=None):
         """(roofline of the trunk convolution or None, roofline of the tree kernel or None) of one measure() result.
@@ -644,6 +652,24 @@ def main():
                 out["roofline"]["kernel_only"] = {"avg_launch_ms": c1["avg_launch_ms"], "boards_per_launch": c1["boards_per_launch"],
                                                   "achieved": c1["achieved"], "frac": c1["frac"], "timing": c1["timing"],
                                                   "from": "one_population_pass"}
+                if M1.get("kinds"):
+                    # the four launches of a forward are different kernels since round 4: the first carries the stem, the last the
+                    # head convolutions and the FC layers.  Each does ONE trunk convolution's flops; `plain` and `residual` are the
+                    # bare convolution (the figure comparable with earlier rounds' kernel-alone fraction)
+                    bv = {}
+                    for k, (ms, n) in M1["kinds"].items():
+                        if n > 0:
+                            avg = ms / n
+                            tfk = c1["boards_per_launch"] * c1["flop_per_board"] / (avg * 1e-3) / 1e12
+                            bv[k] = {"launches": n, "avg_launch_ms": avg, "achieved": tfk, "frac": tfk / MFMA_F32_PEAK_TF}
+                    out["roofline"]["kernel_only"]["by_variant"] = bv
+                    bare = [bv[k] for k in ("plain", "residual") if k in bv]
+                    if bare:
+                        nb_ = sum(b["launches"] for b in bare)
+                        avg_b = sum(b["avg_launch_ms"] * b["launches"] for b in bare) / nb_
+                        tfb = c1["boards_per_launch"] * c1["flop_per_board"] / (avg_b * 1e-3) / 1e12
+                        out["roofline"]["kernel_only"]["bare_convolution"] = {"avg_launch_ms": avg_b, "achieved": tfb,
+                                                                              "frac": tfb / MFMA_F32_PEAK_TF}
             if tree_rl is not None and t1 is not None:
                 out["roofline_tree"]["kernel_only"] = {"avg_launch_ms": t1["avg_launch_ms"], "achieved": t1["achieved"], "frac": t1["frac"],
                                                        "from": "one_population_pass"}

@@ -198,6 +198,10 @@ int sprl_engine_stats(sprl_engine* e, sprl_stats* out);
  * the same HIP events; sum_ms = the sum of the durations.  kind 0 = tree kernel, 1 = trunk convolution of the network plugin.
  * Call sprl_engine_stats on every engine first (it resolves the pending events).  With one engine busy_ms == sum_ms. */
 int sprl_profile_busy(int kind, double* busy_ms, double* sum_ms);
+/* profile = 2 (one HIP-event pair per convolution launch): time in ms and number of the trunk-convolution launches by kind -
+ * [0] plain, [1] with residual input, [2] with the stem in its prologue, [3] with the head convolutions / FC layers behind it.
+ * Lets a report separate the bare convolution from the launches that carry the stem / the tail (boards up to 8x8). */
+int sprl_engine_conv_kinds(sprl_engine* e, double* ms4, int64_t* launches4);
 void sprl_profile_busy_reset(void);
 
 /* Expanded training samples exactly as the reference worker emits them (selfplay/GridWorker.hpp:146-196):

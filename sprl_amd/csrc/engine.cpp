@@ -84,6 +84,7 @@ struct TorchPlugin {
     void (*release)(void*) = nullptr;
     int (*is_native)(void*) = nullptr;
     int (*path_info)(void*, char*, int) = nullptr;
+    void (*profile_read_kinds)(void*, double*, int64_t*) = nullptr;
     int (*forward_dev)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int) = nullptr;
     void (*profile_enable)(void*, int) = nullptr;
     void (*profile_read)(void*, double*, int64_t*, int64_t*) = nullptr;
@@ -182,6 +183,7 @@ int load_torch_plugin(sprl_engine* e) {
     e->torch.release = (void (*)(void*))dlsym(lib, "sprl_torch_free");
     e->torch.is_native = (int (*)(void*))dlsym(lib, "sprl_torch_is_native");
     e->torch.path_info = (int (*)(void*, char*, int))dlsym(lib, "sprl_torch_path_info");
+    e->torch.profile_read_kinds = (void (*)(void*, double*, int64_t*))dlsym(lib, "sprl_torch_profile_read_kinds");
     e->torch.forward_dev = (int (*)(void*, const float*, const unsigned*, int, int, int, int, float*, int, float*, void*, char*, int))dlsym(
         lib, "sprl_torch_forward_dev");
     e->torch.profile_enable = (void (*)(void*, int))dlsym(lib, "sprl_torch_profile_enable");
@@ -689,6 +691,18 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
     if (games_done) *games_done = (int32_t)c.games_done;
     if (active_slots) *active_slots = (int32_t)c.active_slots;
     return check_device_error(e, c);
+}
+
+// profile = 2: time (ms) and launches of the trunk-convolution launches by kind - 0 plain, 1 with residual, 2 with the stem in its
+// prologue, 3 with the heads / FC layers behind it
+int sprl_engine_conv_kinds(sprl_engine* e, double* ms4, int64_t* launches4) {
+    if (!e || !ms4 || !launches4) return fail(SPRL_E_CONFIG, "null argument");
+    for (int k = 0; k < 4; ++k) {
+        ms4[k] = 0.0;
+        launches4[k] = 0;
+    }
+    if (e->torch_model && e->torch.profile_read_kinds && e->cfg.profile) e->torch.profile_read_kinds(e->torch_model, ms4, launches4);
+    return 0;
 }
 
 // network evaluations queued by each game of the current / last self-play run (game index = the order games were started in)

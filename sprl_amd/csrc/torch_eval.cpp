@@ -146,8 +146,14 @@ struct ConvProfile {
     bool per_launch = false;             // mode 2: one event pair per convolution launch (kernel durations comparable with a profiler's
                                          // per-kernel average; costs two queue packets per launch - never used in a timed region)
     std::vector<hipEvent_t> ev;          // pairs (start, end), resolved lazily
+    std::vector<int> ev_kind;            // per pair: the kind of its (last) launch - meaningful in per-launch mode
     double ms = 0.0;
     int64_t launches = 0, boards = 0;
+    // per-launch mode: time and launches by kind of trunk-convolution launch: 0 = plain (no residual), 1 = with residual,
+    // 2 = with the stem in its prologue, 3 = with the heads (and FC layers) behind it
+    double kind_ms[4] = { 0.0, 0.0, 0.0, 0.0 };
+    int64_t kind_launches[4] = { 0, 0, 0, 0 };
+    int open_kind = 0;
     busy::Chain chain;                   // the same intervals on the process-wide clock (several models on several streams)
     // The trunk convolutions of a forward follow each other on the stream with nothing between them, so ONE pair of events brackets
     // all of them (open before the first, note per launch, close behind the last): an event record is a packet of its own in the
@@ -161,10 +167,11 @@ struct ConvProfile {
         if (open_ev) (void)hipEventRecord(open_ev, st);
         open_launches = open_boards = 0;
     }
-    void note(int64_t nboards) {
+    void note(int64_t nboards, int kind = 0) {
         if (!open_ev) return;
         open_launches++;
         open_boards += nboards;
+        open_kind = kind;
     }
     void close(hipStream_t st) {
         if (!open_ev) return;
@@ -177,6 +184,7 @@ struct ConvProfile {
         (void)hipEventRecord(e1, st);
         ev.push_back(open_ev);
         ev.push_back(e1);
+        ev_kind.push_back(open_kind);
         open_ev = nullptr;
         launches += open_launches;
         boards += open_boards;
@@ -190,9 +198,14 @@ struct ConvProfile {
             (void)hipEventSynchronize(ev[i + 1]);
             iv.push_back(chain.resolve(ev[i], ev[i + 1], &t));
             ms += t;
+            if (per_launch) {
+                kind_ms[ev_kind[i / 2] & 3] += t;
+                kind_launches[ev_kind[i / 2] & 3]++;
+            }
             busy::put_event(ev[i + 1]);
         }
         ev.clear();
+        ev_kind.clear();
         g_conv_busy.add(iv);
     }
     ~ConvProfile() {
@@ -358,7 +371,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
         const int rc = sprl_wino_conv64_dev(src.data_ptr<float>(), u.data_ptr<float>(), sc.data_ptr<float>(), sh.data_ptr<float>(),
                                             res, dst.data_ptr<float>(), B, H, W, 1, batch_dev, stream);
         if (prof) {
-            prof->note(B);
+            prof->note(B, res ? 1 : 0);
             if (prof->per_launch) {                  // close this launch's pair, open the next one's
                 prof->close((hipStream_t)stream);
                 prof->open((hipStream_t)stream);
@@ -377,7 +390,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                                                  n.stem_shift.data_ptr<float>(), x.data_ptr<float>(), b.u1.data_ptr<float>(), b.s1.data_ptr<float>(),
                                                  b.t1.data_ptr<float>(), y.data_ptr<float>(), B, H, W, batch_dev, stream);
             if (prof) {
-                prof->note(B);
+                prof->note(B, 2);
                 if (prof->per_launch) {
                     prof->close((hipStream_t)stream);
                     prof->open((hipStream_t)stream);
@@ -396,7 +409,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                                                          stream);
                 if (rc == 0) {
                     if (prof) {
-                        prof->note(B);
+                        prof->note(B, 3);
                         prof->close((hipStream_t)stream);
                     }
                     mdl->last_tail = 2;
@@ -412,7 +425,7 @@ bool forward_wino(Model* mdl, const at::Tensor& in, at::Tensor& p, at::Tensor& v
                                                   n.heads_w.data_ptr<float>(), n.heads_b.data_ptr<float>(), maps.data_ptr<float>(),
                                                   stream);
             if (prof) {
-                prof->note(B);
+                prof->note(B, 3);
                 prof->close((hipStream_t)stream);
             }
             if (rc != 0) return false;
@@ -769,6 +782,17 @@ void sprl_torch_profile_read(void* handle, double* conv_ms, int64_t* launches, i
     if (conv_ms) *conv_ms = p.ms;
     if (launches) *launches = p.launches;
     if (boards) *boards = p.boards;
+}
+
+// per-launch mode (profile 2): time and launches by kind of trunk-convolution launch - 0 plain, 1 with residual, 2 with the stem in
+// its prologue, 3 with the heads / FC layers behind it (boards up to 8x8; the any-board path counts everything as 0 / 1)
+void sprl_torch_profile_read_kinds(void* handle, double* ms4, int64_t* launches4) {
+    ConvProfile& p = static_cast<Model*>(handle)->prof;
+    p.resolve();
+    for (int k = 0; k < 4; ++k) {
+        if (ms4) ms4[k] = p.kind_ms[k];
+        if (launches4) launches4[k] = p.kind_launches[k];
+    }
 }
 
 // The whole forward with the batch size read ON THE DEVICE (`batch_dev`, <= max_batch): nothing here depends on the host

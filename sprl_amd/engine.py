@@ -110,6 +110,7 @@ def load_library(path=None):
     L.sprl_engine_set_forward.argtypes = [C.c_void_p, FORWARD_FN, C.c_void_p]
     L.sprl_engine_evaluator_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.sprl_engine_game_evals.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.sprl_engine_conv_kinds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.sprl_engine_run.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Records)]
     L.sprl_engine_begin.argtypes = [C.c_void_p, C.c_int32]
     L.sprl_engine_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -255,6 +256,12 @@ class Engine:
         buf = C.create_string_buffer(768)
         self._check(self._lib.sprl_engine_evaluator_info(self._h, buf, 768))
         return buf.value.decode()
+
+    def conv_kinds(self):
+        """profile = 2: {kind: (ms, launches)} of the trunk-convolution launches: plain / residual / stem / heads."""
+        ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
+        self._check(self._lib.sprl_engine_conv_kinds(self._h, ms, n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(("plain", "residual", "stem", "heads"))}
 
     def game_evals(self, num_games):
         """Network evaluations queued by each of the first `num_games` games of the current / last self-play run."""

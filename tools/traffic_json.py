@@ -26,7 +26,8 @@ def summary(name):
 def variant(kname):
     inside = kname.split("wino_conv64_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").split(",")
     heads, res = int(inside[2]), int(inside[3]) if len(inside) > 3 else 1
-    return f"HEADS={heads},RES={res}", heads, res
+    stem = int(inside[4]) if len(inside) > 4 else 0
+    return f"HEADS={heads},RES={res},STEM={stem}", heads, res, stem
 
 
 bench = json.load(open(os.path.join(src, f"{tag}_bench.json")))
@@ -38,14 +39,15 @@ sqv = {}
 for k in fetch:
     if "wino_conv64_kernel<8, 8" not in k:
         continue
-    name, heads, res = variant(k)
+    name, heads, res, stem = variant(k)
     n, f_kb = fetch[k]["FETCH_SIZE"]
     _, w_kb = write[k]["WRITE_SIZE"]
     hbm = (2.0 * f_kb + w_kb) * 1024.0
     # per board and launch: 16 KB of activations in, + 16 KB residual (RES), + 16 KB out (or 768 B of head maps with HEADS)
     # (HEADS = 1: 768 B of head maps; HEADS = 2, round 4: the forward ends in the launch - 65 logits + 1 value = 264 B - and the
     # 50 KB of FC weights come from L2)
-    algo = boards * (16384 + (16384 if res else 0) + (264 if heads == 2 else 768 if heads else 16384))
+    # STEM = 1 (round 4): the launch reads the 768 B of input planes, writes x0 (16 KB) and reads it back through L2 (no HBM bytes)
+    algo = boards * ((768 + 16384 if stem else 16384) + (16384 if res else 0) + (264 if heads == 2 else 768 if heads else 16384))
     per[name] = {"FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb, "launches": n, "hbm_bytes_per_launch": hbm, "algorithmic": algo}
     tot_b += hbm * n
     tot_a += algo * n
@@ -62,8 +64,8 @@ with open(os.path.join(src, f"{tag}_bench_kernel_stats.csv"), newline="") as f:
         kt[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]))
 conv_calls = sum(c for k, (c, a) in kt.items() if "wino_conv64_kernel<8, 8" in k)
 conv_avg = sum(c * a for k, (c, a) in kt.items() if "wino_conv64_kernel<8, 8" in k) / max(1, conv_calls) / 1e6
-conv = {"kernel": "wino_conv64_kernel<8,8,HEADS,RES> (cnn_wino.hip; per forward of the 2-block net: RES = 0, RES = 1, RES = 0, and the last one with "
-                  "the head convolutions and the FC layers fused, HEADS = 2)",
+conv = {"kernel": "wino_conv64_kernel<8,8,HEADS,RES,STEM> (cnn_wino.hip; per forward of the 2-block net: STEM = 1 (the stem in its prologue), RES = 1, "
+                  "RES = 0, and the last one with the head convolutions and the FC layers fused, HEADS = 2)",
         "command": f"python bench.py --populations 1 (4096 games, 800 it/move, CNN), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes "
                    f"(tools/profile_round.sh {tag} wino_conv64_kernel; tools/traffic_json.py {tag})",
         "per_variant": per, "fetch_correction": 2.0, "write_correction": 1.0,
