@@ -10,6 +10,7 @@ torch.distributed initialised (backend "nccl" = RCCL) every rank trains on the s
 gradient all-reduce (DistributedDataParallel) — the reference's `prototype/ddp.py` ambition.
 """
 import copy
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -18,6 +19,12 @@ import torch
 from .network import trace_to_bytes, trace_to_file
 
 EPS = 1e-8  # othello_controller.py:150
+
+# Library tuning for the training step on ROCm (round 4, profiles/r04z_trainer_variants.txt: 2.60 -> 2.17 ms per step of batch 1024):
+# MIOpen's im2col + GEMM convolution family works one image at a time (hundreds of tiny launches per step when its heuristic
+# picks it) - left out of its choice, as the evaluator plugin does (torch_eval.cpp); and train_network lets the library MEASURE its
+# solvers per shape (cudnn.benchmark) instead of guessing.  Both only select among the library's fp32 kernels.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_GEMM", "0")
 
 
 @dataclass
@@ -175,6 +182,12 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
     and early-stop decisions: every rank takes the same decisions and exports the same weights."""
     s, d, o, t = tensors
     device = s.device
+    if device.type == "cuda" and not torch.backends.cudnn.benchmark:
+        torch.backends.cudnn.benchmark = True                                   # (see the note at the top of the file)
+        try:
+            return train_network(net, learning_rate, tensors, cfg, generator, ddp, log, index_plan)
+        finally:
+            torch.backends.cudnn.benchmark = False
     net.to(device)
     n = s.shape[0]
     dist = _dist() if ddp else None
