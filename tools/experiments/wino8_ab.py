@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
@@ -92,7 +92,7 @@ def main():
                 assert err < 1e-4
             t0 = timeit(0, 2, with_res)
             print(f"  res={int(with_res)} one workgroup per group                  {t0:8.1f} us   {flop / t0 / 1e6 / 157.3:.3f}")
-            for npre in (2, 3):
+            for npre in (2,):
                 for grid in a.grids:
                     y.fill_(float("nan"))
                     assert run(grid, npre, with_res) == 0
