@@ -429,7 +429,8 @@ __global__ void __launch_bounds__(256) tail_heads_value_kernel(const float* __re
                                                                const float* __restrict__ vfc2_b, float* __restrict__ pmaps,
                                                                float* __restrict__ value, int batch, int HW, int PC, int HID,
                                                                const unsigned* __restrict__ batch_dev, int tile_m, int Wb) {
-    // tile_m = 0: x is NCHW; 3 / 4: x is layout T of the any-board trunk kernel (board width Wb)
+    // tile_m = 0: x is NCHW; 3 / 4: x is layout T of the any-board trunk kernel (board width Wb; row pitch = capacity x tiles)
+    const int cap = batch;
     if (batch_dev) {
         const int real = (int)*batch_dev;
         batch = real < batch ? real : batch;
@@ -456,10 +457,11 @@ __global__ void __launch_bounds__(256) tail_heads_value_kernel(const float* __re
             const int Hb = HW / Wb, row = cell / Wb, col = cell - row * Wb;
             const int TXt = (Wb + tile_m - 1) / tile_m, TPB = TXt * ((Hb + tile_m - 1) / tile_m), MC = tile_m * tile_m;
             const int cell_t = (row % tile_m) * tile_m + col % tile_m, tile_t = (row / tile_m) * TXt + col / tile_m;
-            const tf4* xp = (const tf4*)x + ((size_t)(n0 + b) * 16 * MC + cell_t) * TPB + tile_t;
+            const size_t TT = (size_t)cap * TPB;
+            const tf4* xp = (const tf4*)x + (size_t)cell_t * TT + (size_t)(n0 + b) * TPB + tile_t;
 #pragma unroll 4
             for (int q = 0; q < 16; ++q) {
-                const tf4 v = xp[(size_t)q * MC * TPB];
+                const tf4 v = xp[(size_t)q * MC * TT];
 #pragma unroll
                 for (int o = 0; o < OC; ++o)
                     acc[o] += s_hw[o * 64 + 4 * q] * v[0] + s_hw[o * 64 + 4 * q + 1] * v[1] + s_hw[o * 64 + 4 * q + 2] * v[2] + s_hw[o * 64 + 4 * q + 3] * v[3];
@@ -625,8 +627,9 @@ __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __r
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              float* __restrict__ y, long long cells, int H, int W,
                                                              const unsigned* __restrict__ batch_dev, int tile_m) {
-    // tile_m = 0: y is NCHW; 3 or 4: y is layout T of the any-board trunk kernel (cnn_wino.hip): [n][q][cell][tile][4 channels]
+    // tile_m = 0: y is NCHW; 3 or 4: y is layout T of the any-board trunk kernel (cnn_wino.hip): [q][cell][n * tiles + tile][4 channels]
     constexpr int PG = (P + 3) / 4, KS = PG * 9;
+    const long long cap_boards = cells / ((long long)H * W);      // layout T: the row pitch is capacity x tiles per board
     if (batch_dev) {                                   // the real board count is on the device; `cells` is the capacity
         const long long real = (long long)*batch_dev * H * W;
         cells = real < cells ? real : cells;
@@ -695,7 +698,7 @@ __global__ void __launch_bounds__(256, 3) stem_mfma_nchw_kernel(const float* __r
                     const float t = acc[kb][r] * scsh[0][k] + scsh[1][k];
                     v[r] = t > 0.0f ? t : 0.0f;
                 }
-                *(stem_f4*)(y + ((((size_t)n * 16 + 4 * kb + qs) * MC + cell_t) * TPB + tile_t) * 4) = v;
+                *(stem_f4*)(y + (((size_t)(4 * kb + qs) * MC + cell_t) * (size_t)(cap_boards * TPB) + (size_t)n * TPB + tile_t) * 4) = v;
             }
         } else if (live) {
             float* yo = y + ((size_t)n * 64) * HW + cell;

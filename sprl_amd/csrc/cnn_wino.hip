@@ -732,9 +732,13 @@ __device__ __forceinline__ void inverse_rows(const float (&m)[M + 2][M + 2], flo
 //          float at a time).  tools/nchw_lab.py (profiles/r03h_nchw_lab_*.log) showed that form bound by its memory INSTRUCTIONS,
 //          not by bandwidth or MFMA: at 8192 9x9 boards 361 us, of which the output stores 96 us, the activation loads 89 us, the
 //          residual loads 49 us - while the MFMA loop + transforms alone run in 185 us.
-// LAY = 1: layout T, made for this kernel:  x[n][q][cell][tile][e]  with channel 4 q + e, cell = i * M + j inside the M x M tile,
-//          tile = ty * TX + tx; 64 * M^2 * tiles floats per board (9x9 with M = 3: exactly 64 * 81, no padding; 19x19 with M = 4:
-//          64 * 400).  Every global access is then an aligned 16-byte vector of four channels, and lanes that hold neighbouring
+// LAY = 1: layout T, made for this kernel:  x[q][cell][n * tiles + tile][e]  with channel 4 q + e, cell = i * M + j inside the
+//          M x M tile, tile = ty * TX + tx, n = board; the tile index runs over the whole BATCH (round 4; before: x[n][q][cell]
+//          [tile][e]), so the 16 consecutive tiles of a workgroup are ONE aligned 256-byte row per (q, cell) whatever boards
+//          they belong to - with the board-major form a workgroup's rows were cut at board boundaries into unaligned pieces and
+//          the kernel moved 1.46 x (9x9) / 1.67 x (19x19) its algorithmic bytes through HBM (profiles/conv_kernel_traffic_go*.json).
+//          64 * M^2 * tiles floats per board (9x9 with M = 3: exactly 64 * 81, no padding; 19x19 with M = 4: 64 * 400); the
+//          row pitch is cap * tiles, cap = the `batch` argument (the capacity when the count is on the device).  Every global access is then an aligned 16-byte vector of four channels, and lanes that hold neighbouring
 //          tiles touch neighbouring vectors: a patch is (M+2)^2 vector loads shared over 8 loader threads per (tile, channel quad),
 //          an output tile M^2 vector stores, the residual M^2 vector loads.  Cells of a tile that lie off the board are never read
 //          (the loader answers them with zero through the range check) and may hold anything.
@@ -747,11 +751,13 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     constexpr int PT = Gm::PT, NP = Gm::NP, NQ = Gm::NQ, PS = Gm::PS, SS = Gm::SS, IN_BUF = Gm::IN_BUF, VG = Gm::VG, NLD = Gm::NLD;
     // batch_dev != null: the number of boards is on the device (the engine's leaf count of this round), `batch` is the capacity
     // the grid was sized for; workgroups whose 16 tiles lie past the real count leave at once
+    const int cap = batch;                            // boards the activation buffers are laid out for (layout T: see TT)
     if (batch_dev) {
         const int real = (int)*batch_dev;
         batch = real < batch ? real : batch;
     }
     const int TX = (W + M - 1) / M, TY = (H + M - 1) / M, TPB = TX * TY;
+    const int TT = cap * TPB;                         // layout T: tiles of the whole buffer - the tile index runs over the BATCH
     if ((long long)blockIdx.x * 16 >= (long long)batch * TPB) return;
     __shared__ __attribute__((aligned(16))) float lds[Gm::LDS_FLOATS];
     float* const in_buf = lds;
@@ -784,7 +790,8 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     // past the batch) gets bit 31 set in its offset, which the hardware range check answers with 0 for loads and drops for
     // stores (the host keeps the tensors below 2 GiB) - no predicated loads, no branches, no 64-bit address arithmetic.
     constexpr int OOB = (int)0x80000000;
-    const unsigned act_bytes = LAY ? (unsigned)batch * (unsigned)(64 * MC * TPB * 4) : (unsigned)batch * 64u * (unsigned)HW * 4u;
+    // (layout T interleaves the boards: the range check cannot cut at the real count, tiles past it carry t_n = -1 -> OOB)
+    const unsigned act_bytes = LAY ? (unsigned)cap * (unsigned)(64 * MC * TPB * 4) : (unsigned)batch * 64u * (unsigned)HW * 4u;
     // the input descriptor starts 16 bytes before x: a patch's first column is col0 - 1, so with the bias no offset is ever
     // negative (a negative per-lane offset plus a positive instruction offset must not depend on how the range check wraps)
     // A patch row (6 or 5 floats) is one 16-byte + one 8- or 4-byte load and a residual row one 16-byte load, at 4-byte alignment;
@@ -813,7 +820,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         const int pc = ld_part + 8 * e;
         const int R = t_row0 + pc / PT - 1, Cc = t_col0 + pc % PT - 1;
         const bool ok = LAY && pc < NP && t_n >= 0 && R >= 0 && R < H && Cc >= 0 && Cc < W;
-        ld_toff[e] = ok ? (((t_n * 16 + ld_quad) * MC + (R % M) * M + Cc % M) * TPB + (R / M) * TX + Cc / M) * 16 : OOB;
+        ld_toff[e] = ok ? ((ld_quad * MC + (R % M) * M + Cc % M) * TT + t_n * TPB + (R / M) * TX + Cc / M) * 16 : OOB;
     }
     // DEEP (layout T, F(3x3,3x3)): a phase of this tiling is only 50 MFMAs per wave (0.7 us), shorter than a trip to HBM, and
     // tools/nchw_lab.py showed the kernel waiting on its own prefetches (with the MFMA loop removed it lost only 28 % of its
@@ -827,7 +834,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         if constexpr (LAY == 1) {
 #pragma unroll
             for (int e = 0; e < NPC; ++e) {
-                const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_toff[e], chunk * (2 * MC * 16) * TPB, 0));
+                const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_toff[e], chunk * (2 * MC * 16) * TT, 0));
                 pre[4 * e] = v[0]; pre[4 * e + 1] = v[1]; pre[4 * e + 2] = v[2]; pre[4 * e + 3] = v[3];
             }
             return;
@@ -974,13 +981,13 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     constexpr int NR_T = M == 4 ? 2 : M;               // rows per output band (see the output stage)
     constexpr bool EARLY_RES = RES && LAY == 1;
     const int q_out = 4 * kb + c_sub;                  // layout T: this lane's output channels 4 q_out .. 4 q_out + 3
-    const int obase = (LAY == 1 && t_n >= 0) ? ((t_n * 16 + q_out) * MC * TPB + t_tt) * 16 : OOB;
+    const int obase = (LAY == 1 && t_n >= 0) ? (q_out * MC * TT + tg) * 16 : OOB;
     f4 rv0[EARLY_RES ? NR_T * M : 1];
     auto early_res = [&]() {
         if constexpr (EARLY_RES) {
 #pragma unroll
             for (int cc = 0; cc < NR_T * M; ++cc)
-                rv0[cc] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + cc * TPB * 16, 0, 0));
+                rv0[cc] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + cc * TT * 16, 0, 0));
         }
     };
     auto phase = [&](int c, float* pre) {
@@ -1040,7 +1047,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
 #pragma unroll
                 for (int c = 0; c < NR * M; ++c) {
                     if (band == 0) rv[c] = rv0[EARLY_RES ? c : 0];      // (requested during the last K steps)
-                    else rv[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + (band * NR * M + c) * TPB * 16, 0, 0));
+                    else rv[c] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + (band * NR * M + c) * TT * 16, 0, 0));
                 }
             }
 #pragma unroll
@@ -1066,7 +1073,7 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
                 }
                 if (LAB_OFF(4) && v[0] != 12345.0f) continue;      // lab: no output stores
                 // (per-lane offset + nothing else: no scalar-register offset on a 16-byte store - the gfx950 store hazard)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, obase + (band * NR * M + c) * TPB * 16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, obase + (band * NR * M + c) * TT * 16, 0, 0);
             }
         }
         return;

@@ -151,19 +151,22 @@ def test_wino_conv_general_boards_nchw(plug, H, W, B, tile):
 
 
 def to_layout_t(x, M):
-    """[B][64][H][W] -> layout T of the any-board trunk kernel: [B][q = 16][cell = M*M][tile][4 channels] (cnn_wino.hip)."""
+    """[B][64][H][W] -> layout T of the any-board trunk kernel: [q = 16][cell = M*M][n * tiles + tile][4 channels] (cnn_wino.hip;
+    the tile index runs over the batch)."""
     import torch
     B, _, H, W = x.shape
     TY, TX = (H + M - 1) // M, (W + M - 1) // M
     xp = torch.zeros(B, 64, TY * M, TX * M, device=x.device, dtype=x.dtype)
     xp[:, :, :H, :W] = x
-    return xp.view(B, 16, 4, TY, M, TX, M).permute(0, 1, 4, 6, 3, 5, 2).reshape(B, 16, M * M, TY * TX, 4).contiguous()
+    # [B][q][e][ty][i][tx][j] -> [q][i][j][B][ty][tx][e]
+    return xp.view(B, 16, 4, TY, M, TX, M).permute(1, 4, 6, 0, 3, 5, 2).reshape(16, M * M, B * TY * TX, 4).contiguous()
 
 
 def from_layout_t(t, M, H, W):
-    B = t.shape[0]
     TY, TX = (H + M - 1) // M, (W + M - 1) // M
-    return t.view(B, 16, M, M, TY, TX, 4).permute(0, 1, 6, 4, 2, 5, 3).reshape(B, 64, TY * M, TX * M)[:, :, :H, :W]
+    B = t.shape[2] // (TY * TX)
+    # [q][i][j][B][ty][tx][e] -> [B][q][e][ty][i][tx][j]
+    return t.view(16, M, M, B, TY, TX, 4).permute(3, 0, 6, 4, 1, 5, 2).reshape(B, 64, TY * M, TX * M)[:, :, :H, :W]
 
 
 @pytest.mark.parametrize("tile", [4, 3])
@@ -210,7 +213,8 @@ def test_wino_conv_general_boards_layout_t(plug, H, W, B, tile):
                                      y2t.data_ptr(), B, H, W, int(relu), tile, cnt.data_ptr(), None)
         assert rc == 0
         torch.cuda.synchronize()
-        assert torch.equal(from_layout_t(y2t[:live], tile, H, W), y[:live]) and torch.isnan(y2t[live:]).all()
+        y2 = from_layout_t(y2t, tile, H, W)
+        assert torch.equal(y2[:live], y[:live]) and torch.isnan(y2[live:]).all()
 
 
 @pytest.mark.parametrize("P,H,W,B,tile", [(17, 9, 9, 7, 3), (17, 19, 19, 3, 4), (3, 13, 6, 11, 4), (17, 9, 9, 513, 3), (3, 9, 9, 1, 4)])
@@ -225,7 +229,7 @@ def test_stem_any_board_layout_t(plug, P, H, W, B, tile):
     want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1)
                       + shift.double().view(1, -1, 1, 1))
     TY, TX = (H + tile - 1) // tile, (W + tile - 1) // tile
-    yt = torch.full((B, 16, tile * tile, TY * TX, 4), float("nan"), device="cuda")
+    yt = torch.full((16, tile * tile, B * TY * TX, 4), float("nan"), device="cuda")
     rc = plug.sprl_stem_conv3x3_t(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(), yt.data_ptr(), B, P, H, W, tile, None, None)
     assert rc == 0
     torch.cuda.synchronize()
