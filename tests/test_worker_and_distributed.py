@@ -327,3 +327,31 @@ def test_native_worker_backs_off_when_device_memory_runs_out(tmp_path):
     half, got = run(tmp_path / "c", SPRL_EMU_HBM_BYTES=str(peak - 1200 * 1024))
     assert "HBM holds 2 of the 4 games at once" in half.stdout or "HBM holds 1 of the 4 games at once" in half.stdout, half.stdout
     assert got == want
+
+
+def test_timeline_tool_on_a_synthetic_trace(tmp_path):
+    """tools/timeline.py (the overlap / idle / gap statistics of DESIGN.md section 5) on a hand-made two-queue kernel trace: queue 1
+    runs a convolution 0-100 us and a tree kernel 110-150 us, queue 2 a convolution 50-130 us: busy 150 us of 150, two kernels
+    together during 50-100 and 110-130, one 10 us gap on queue 1."""
+    import csv
+    import json
+    import sys
+    rows = [("1", "wino_conv64_kernel<8, 8, 0, 1, 0>(...)", 0, 100_000), ("1", "step_kernel<Othello>(EngineParams)", 110_000, 150_000),
+            ("2", "wino_conv64_kernel<8, 8, 0, 0, 1>(...)", 50_000, 130_000)]
+    path = tmp_path / "kernel_trace.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kind", "Agent_Id", "Queue_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        for q, name, s, e in rows:
+            w.writerow(["KERNEL_DISPATCH", "0", q, name, 1_000_000 + s, 1_000_000 + e])
+    out = tmp_path / "tl.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), str(path), "--skip", "0", "--json", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tl = json.load(open(out))
+    assert abs(tl["wall_ms"] - 0.150) < 1e-9 and abs(tl["busy_any_share"] - 1.0) < 1e-9
+    assert abs(tl["busy_two_or_more_share"] - 70 / 150) < 1e-9 and tl["queues"] == 2
+    assert tl["classes"]["conv"]["launches"] == 2 and tl["classes"]["tree"]["launches"] == 1
+    assert abs(tl["classes"]["conv"]["mean_us"] - 90.0) < 1e-9
+    assert abs(tl["gaps"]["1"]["mean_us"] - 10.0) < 1e-9
