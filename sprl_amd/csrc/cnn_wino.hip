@@ -826,7 +826,10 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
     // tools/nchw_lab.py showed the kernel waiting on its own prefetches (with the MFMA loop removed it lost only 28 % of its
     // time).  There are registers to spare at 100 accumulators, so the activation chunks are requested TWO phases ahead (two
     // register sets, phases unrolled in pairs) and the filter quads two K steps ahead (two rings).
-    constexpr bool DEEP = LAY == 1 && M == 3;         // filter rings two K steps deep
+#ifndef SPRL_WINO_F3_RINGS
+#define SPRL_WINO_F3_RINGS 2                          // lab: 1 = one filter ring (quads one K step ahead) in the F(3x3) layout-T kernel
+#endif
+    constexpr bool DEEP = LAY == 1 && M == 3 && SPRL_WINO_F3_RINGS == 2;     // filter rings two K steps deep
     constexpr bool DEEP_ACT = LAY == 1 && (M == 3 || SPRL_WINO_DEEP4);      // activation chunks two phases deep
     float pre0[LAY ? 4 * NPC : NLD], pre1[DEEP_ACT ? 4 * NPC : 1];
     auto gload = [&](int chunk, float* pre) {
