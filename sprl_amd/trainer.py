@@ -38,6 +38,13 @@ class TrainerConfig:
     num_past_iters_to_train: int = 10      # :47
     linear_weighting: bool = True          # :45
     val_fraction: float = 0.1              # :135-136
+    fast_conv: bool = False                # the residual trunk's 3x3 convolutions (forward and backward-data) on the hand-written
+                                           # Winograd / fp32-MFMA kernel instead of the library's (trainer_ops.WinoConv3x3).  Correct
+                                           # (tests/test_gpu_cnn.py) and measured (profiles/r04zh_*, r04zj_*): the convolution itself
+                                           # takes 21 us where the library's takes 90-120, but the two layout conversions and the filter
+                                           # transform around every call bring the op to ~50 us and five launches - +5 % with the graph
+                                           # replay, SLOWER in the eager loop.  Off until BatchNorm / ReLU / the residual add live in
+                                           # layout W too
     use_graph: bool = True                 # MI355X: replay the optimiser step (gather, forward, losses, backward, AdamW) from ONE
                                            # captured HIP graph per full-size batch instead of ~100 kernel launches: the eager step
                                            # is bound by its launches (round 4: 6.5 -> 2.4 ms per step incl. validation on a GPU box
@@ -98,6 +105,16 @@ def _evaluate(net, tensors, batches):
     count]: nothing is read back per batch, the caller synchronises once per epoch."""
     s, d, o, t = tensors
     acc = torch.zeros(3, device=s.device, dtype=torch.float64)
+    measure = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False               # (forward-only shapes, the last one of a size of its own: no solver search)
+    try:
+        return _evaluate_batches(net, tensors, batches, acc)
+    finally:
+        torch.backends.cudnn.benchmark = measure
+
+
+def _evaluate_batches(net, tensors, batches, acc):
+    s, d, o, t = tensors
     with torch.no_grad():
         for b in batches:
             lo, va = net(s[b])
@@ -188,6 +205,15 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
             return train_network(net, learning_rate, tensors, cfg, generator, ddp, log, index_plan)
         finally:
             torch.backends.cudnn.benchmark = False
+    if cfg.fast_conv and device.type == "cuda" and not ddp and not getattr(net, "_sprl_fast_trunk", False):
+        from . import trainer_ops
+        if trainer_ops.available():
+            net._sprl_fast_trunk = True
+            try:
+                with trainer_ops.fast_trunk(net):
+                    return train_network(net, learning_rate, tensors, cfg, generator, ddp, log, index_plan)
+            finally:
+                del net._sprl_fast_trunk
     net.to(device)
     n = s.shape[0]
     dist = _dist() if ddp else None
@@ -247,6 +273,10 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                     graph_step(b)
                     nb += 1
                     continue
+                # the library measures its solvers per SHAPE: worth it for the full-size batch every step uses, not for the one
+                # short batch at the end of an epoch whose size changes with the window (a search costs about a second per shape)
+                measure = torch.backends.cudnn.benchmark
+                torch.backends.cudnn.benchmark = measure and b.numel() == cfg.batch_size
                 lo, va = model(s[b])
                 pl, vl = weighted_losses(lo, va, d[b], o[b], t[b])
                 opt.zero_grad(set_to_none=True)
@@ -255,6 +285,7 @@ def train_network(net, learning_rate, tensors, cfg: TrainerConfig, generator: Op
                 tacc[0] += pl.detach().double()
                 tacc[1] += vl.detach().double()
                 nb += 1
+                torch.backends.cudnn.benchmark = measure
             if graph_step is not None:
                 graph_step.drain(tacc)
             model.eval()

@@ -259,3 +259,68 @@ def test_stem_any_board_mfma_and_valu_forms(plug, P, H, W, B):
         torch.cuda.synchronize()
         err = (y.double() - want).abs().max().item()
         assert err < 1e-5, (P, H, W, B, valu, err)
+
+
+@pytest.mark.parametrize("H,W,B", [(8, 8, 37), (6, 7, 5), (7, 7, 9), (8, 8, 1030)])
+def test_trainer_conv_op_forward_and_gradients(plug, H, W, B):
+    """sprl_amd/trainer_ops.py: WinoConv3x3 (the trunk convolutions of a TRAINING step on the hand-written kernel) against
+    conv2d + autograd in float64: the output, the input gradient (the same kernel with the filters transposed over the channels
+    and rotated by 180 degrees, brought to the Winograd domain on the device), the weight and bias gradients (the framework's)."""
+    import torch
+    from sprl_amd import trainer_ops as TO
+    assert TO.available()
+    torch.manual_seed(H * 100 + W * 10 + B)
+    x = torch.randn(B, 64, H, W, device="cuda", requires_grad=True)
+    w = (torch.randn(64, 64, 3, 3, device="cuda") * 0.06).requires_grad_()
+    b = (torch.randn(64, device="cuda") * 0.3).requires_grad_()
+    gy = torch.randn(B, 64, H, W, device="cuda")
+    assert TO.supported(x, w)
+    y = TO.WinoConv3x3.apply(x, w, b)
+    y.backward(gy)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    yd = torch.nn.functional.conv2d(xd, wd, bd, padding=1)
+    yd.backward(gy.double())
+    scale = lambda t: float(t.abs().max())
+    assert (y.double() - yd).abs().max().item() < 2e-5 * max(1.0, scale(yd))
+    assert (x.grad.double() - xd.grad).abs().max().item() < 2e-5 * max(1.0, scale(xd.grad))
+    assert (w.grad.double() - wd.grad).abs().max().item() < 1e-4 * max(1.0, scale(wd.grad))
+    assert (b.grad.double() - bd.grad).abs().max().item() < 1e-4 * max(1.0, scale(bd.grad))
+    # the device-side filter transform is the host's (torch_eval.cpp: wino_transform) up to the last bit of the final rounding
+    # (double arithmetic on both sides; the device compiler contracts multiply-adds)
+    import ctypes as C
+    L = TO._lib()
+    L.sprl_wino_transform_weights.argtypes = [C.c_void_p, C.c_void_p]
+    uh = torch.zeros(36 * 64 * 64)
+    wc = w.detach().cpu().contiguous()
+    L.sprl_wino_transform_weights(wc.data_ptr(), uh.data_ptr())
+    ud = torch.empty(36 * 64 * 64, device="cuda")
+    assert L.sprl_train_wino_weights(w.detach().contiguous().data_ptr(), ud.data_ptr(), 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(ud.cpu(), uh, rtol=1e-6, atol=1e-9)
+
+
+def test_trainer_fast_trunk_trains_like_the_library(plug):
+    """train_network with the trunk convolutions on the hand-written kernel and the step replayed from a HIP graph (the defaults)
+    against the plain eager loop on the library's kernels: same data, same seeds - the per-epoch losses agree to 1e-3 relative
+    (different fp32 summation orders through 2 x 3 epochs of AdamW), the best epoch is the same."""
+    import torch
+    from sprl_amd import trainer as T
+    from sprl_amd.network import GridResNet
+    torch.manual_seed(5)
+    n, bs = 8 * 1024, 1024
+    s = (torch.rand(n, 3, 8, 8, device="cuda") > 0.5).float()
+    d = torch.softmax(torch.randn(n, 65, device="cuda"), 1)
+    o = torch.sign(torch.randn(n, 1, device="cuda"))
+    t = torch.ones(n, 1, device="cuda")
+    hist = {}
+    for name, kw in (("fast", dict(fast_conv=True, use_graph=True)), ("plain", dict(fast_conv=False, use_graph=False))):
+        torch.manual_seed(11)
+        net = GridResNet(8, 8, 65, 1, 2, 64)
+        cfg = T.TrainerConfig(batch_size=bs, max_groups=1, epochs_per_group=3, **kw)
+        best, h = T.train_network(net, 0.01, (s, d, o, t), cfg, generator=torch.Generator(device="cuda").manual_seed(3))
+        hist[name] = h
+        assert "forward" not in net.residual_blocks[0].conv1.__dict__          # the patch is gone when train_network returns
+    for a, b in zip(hist["fast"]["epochs"], hist["plain"]["epochs"]):
+        for k in ("train_policy", "train_value", "val_policy", "val_value"):
+            assert abs(a[k] - b[k]) < 2e-3 * max(1.0, abs(b[k])), (k, a, b)
+    assert hist["fast"]["best_epoch"] == hist["plain"]["best_epoch"]
