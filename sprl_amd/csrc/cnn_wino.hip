@@ -138,6 +138,35 @@ struct StemArgs {
 // column x one part x the four boards of the workgroup, at most 32 weights long
 constexpr int FC_MAXA = 96, FC_LP = 32;
 
+// ---- compile-time switches of the kernels below (product values; tools/conv_ab.py and tools/build_plugin_variant.sh build the others) ----
+#ifndef SPRL_WINO_LD_AUX
+#define SPRL_WINO_LD_AUX 2                            // cache policy of the 8x8 kernel's activation / residual loads (2 = nt: streamed)
+#endif
+#ifndef SPRL_WINO_ST_AUX
+#define SPRL_WINO_ST_AUX 2                            // ... and of its output stores (default policy for either: -1.3 / -2.9 % in the bench, profiles/r04zo_*)
+#endif
+#ifndef SPRL_WINO_GLOAD_BRANCH
+#define SPRL_WINO_GLOAD_BRANCH 0                      // lab: 1 = the activation request of a phase sits behind a branch (the round-3 form)
+#endif
+#ifndef SPRL_WINO_PRIO
+#define SPRL_WINO_PRIO 0                              // lab: 8x8 kernel - static priority for one of the two waves of a SIMD (1: odd wave slot, 2: even, 3: odd workgroup)
+#endif
+#ifndef SPRL_WINO_PRIO_LEVEL
+#define SPRL_WINO_PRIO_LEVEL 1
+#endif
+// B operands of a K step (V from LDS) read a fixed number of MFMA pairs AHEAD of their use (rolling, asm reads with counted waits:
+// see the K step of the 8x8 kernel).  Measured per kernel (tools/conv_ab.py, profiles/r04zl_conv_ab_broll.log): the F(4x4) any-board
+// kernel gains 4 % (19x19), the 8x8 kernel nothing (+-1 %: its SIMD's other wave already covers the LDS round trips) and the
+// F(3x3) kernel has no registers for it (61 spilled) - so it is on for F(4x4) only.  0 = the compiler's own batches of eight.
+#ifndef SPRL_WINO_BROLL
+#define SPRL_WINO_BROLL 0                             // 8x8 kernel
+#endif
+#ifndef SPRL_WINO_BROLL_F4
+#define SPRL_WINO_BROLL_F4 4                          // any-board kernel, F(4x4,3x3)
+#endif
+#ifndef SPRL_WINO_BROLL_F3
+#define SPRL_WINO_BROLL_F3 0                          // any-board kernel, F(3x3,3x3)
+#endif
 #ifndef SPRL_WINO_DEEP4
 #define SPRL_WINO_DEEP4 0                             // 1: the F(4x4) layout-T kernel also keeps two activation chunks in flight
 #endif
@@ -146,6 +175,29 @@ __constant__ int wino_lab_dbg;
 #define LAB_OFF(bit) (wino_lab_dbg & (1 << (bit)))
 #else
 #define LAB_OFF(bit) 0
+#endif
+#if defined(SPRL_WINO_LAB) || defined(SPRL_WINO_TRACE)
+// timeline (tools/wino8_trace.py, a build with -DSPRL_WINO_TRACE: the product kernel plus the stamps): lane 0 of every wave of the
+// workgroups [first, first + count) writes the shader clock at the marked points of the 8x8 kernel to
+// trace[(block - first) * 4 + wave][0..63]; stamp 63 is the wave's HW_ID (CU / SIMD / wave slot), 62 its XCC_ID.
+// (`tracing` / `trace_row` are set once at the top of the kernel; the stamps of a phase wait in scalar registers and are written
+// together at its end, so that a traced wave pays one wait for the clock reads per phase)
+#define SPRL_WINO_STAMPS 1
+__device__ unsigned long long* wino_lab_trace;
+__device__ int wino_lab_trace_first, wino_lab_trace_count;
+#define LAB_STAMP(id)                                                                                                              \
+    do {                                                                                                                           \
+        if (tracing) {                                                                                                             \
+            const unsigned long long now_ = clock64();                                                                             \
+            if (lane == 0) trace_row[id] = now_;                                                                                   \
+        }                                                                                                                          \
+    } while (0)
+#define LAB_STAMP_LATER(var) do { if (tracing) var = clock64(); } while (0)
+#define LAB_STAMP_WRITE(id, var) do { if (tracing && lane == 0) trace_row[id] = var; } while (0)
+#else
+#define LAB_STAMP(id) ((void)0)
+#define LAB_STAMP_LATER(var) ((void)0)
+#define LAB_STAMP_WRITE(id, var) ((void)0)
 #endif
 
 constexpr int NIMG2 = 4, NTHR2 = 256;
@@ -167,6 +219,14 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         batch = real < batch ? real : batch;
     }
     if ((int)blockIdx.x * NIMG2 >= batch) return;
+#if SPRL_WINO_PRIO
+    {   // lab (profiles/r04zr_conv_ab_prio.log): a static priority for one of the two waves that share a SIMD (told apart by their
+        // wave slot) - the arbiter already prefers the older wave, so this changes little: +0.6 ... +5.5 % in the lab, nothing in the bench
+        const unsigned hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));      // HW_ID[3:0]: wave slot on the SIMD
+        const bool hi = SPRL_WINO_PRIO == 1 ? (hw_id & 1) : SPRL_WINO_PRIO == 2 ? !(hw_id & 1) : (blockIdx.x & 1);
+        if (hi) __builtin_amdgcn_s_setprio(SPRL_WINO_PRIO_LEVEL);
+    }
+#endif
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS2];
     float* const in_buf = lds;                        // [2][IN_BUF2]
     float* const v_buf = lds + 2 * IN_BUF2;           // [2 phases][2 groups][V_G2]
@@ -177,6 +237,16 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     const int kb = wave;                              // consumer role: output channels 16kb..16kb+15
     const int n0 = (int)blockIdx.x * NIMG2;
 
+#ifdef SPRL_WINO_STAMPS
+    const bool tracing = wino_lab_trace && (int)blockIdx.x >= wino_lab_trace_first && (int)blockIdx.x < wino_lab_trace_first + wino_lab_trace_count;
+    unsigned long long* const trace_row = wino_lab_trace + (((int)blockIdx.x - wino_lab_trace_first) * 4 + wave) * 64;
+    unsigned long long st0_ = 0, st1_ = 0, st2_ = 0, st3_ = 0, st4_ = 0, st5_ = 0;
+    if (tracing && lane == 0) {
+        trace_row[63] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_ID
+        trace_row[62] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));      // XCC_ID
+    }
+#endif
+    LAB_STAMP(0);                                      // wave started
     for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;    // borders stay zero for the whole kernel
 
     int ldst[2], xvoff[2];                            // LDS float index / global byte offset of this thread's two 16-byte pieces of a chunk
@@ -207,8 +277,18 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     f4 pre[2];                                        // the activation chunk in flight
     auto gload_to = [&](int chunk, f4 (&dst)[2]) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-            dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[it], chunk * 2048, 2));
+        for (int it = 0; it < 2; ++it) {
+            if (LAB_OFF(0) && chunk > 2) continue;     // lab: no activation loads behind the prologue's
+            // (lab bit 8: every workgroup reads the first four boards - the same stream of requests, answered by L2 instead of HBM)
+            int voff = LAB_OFF(8) ? xvoff[it] - n0 * 16384 : xvoff[it];
+            // chunk < 0 = "nothing to request": the load is issued all the same, with an offset the range check rejects (no memory
+            // access, zeros come back at once).  A BRANCH around the loads costs more than the loads: the compiler's wait counts
+            // must hold on both paths, so behind a skipped-or-not pair of loads every `vmcnt(n)` of the K step is two too small on
+            // the path that did issue them - and the last filter quads of the step then wait for the HBM trip of the activation
+            // chunk itself (tools/conv_ab.py, profiles/r04zt_conv_ab_request_without_branch.log: +0.2 ... +2.7 %).
+            if (chunk < 0) voff = (int)0x80000000;
+            dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (chunk < 0 ? 0 : chunk) * 2048, SPRL_WINO_LD_AUX));
+        }
     };
     auto lstore_from = [&](float* buf, const f4 (&src)[2]) {
 #pragma unroll
@@ -267,10 +347,50 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     };
     // one K step = one group of 4 input channels: 36 MFMAs; `chunk` >= 0: request that activation chunk behind the filters.
     // FIRST: the accumulators start from the MFMA's constant-zero C operand (no 144-instruction zero fill per wave)
-    auto kstep = [&](const float* vg, int s, int chunk, auto first) {
+    auto kstep = [&](const float* vg, int s, int chunk, auto first, auto with_gload) {
         constexpr bool FIRST = decltype(first)::value;
+        constexpr bool WITH_GLOAD = decltype(with_gload)::value;      // this K step carries the phase's activation request
         __builtin_amdgcn_sched_barrier(0);
-        if (chunk >= 0) gload_to(chunk, pre);
+#if SPRL_WINO_GLOAD_BRANCH
+        if (chunk >= 0) gload_to(chunk, pre);         // lab: the round-3 form
+#else
+        if (WITH_GLOAD) {                              // issued whether or not there is a chunk left to request (see gload_to)
+            gload_to(chunk, pre);
+            __builtin_amdgcn_sched_barrier(0);         // at the HEAD of the K step: as far ahead of the filter quads requested behind it as it gets
+        }
+#endif
+#if SPRL_WINO_BROLL
+        // B operands (V from LDS) requested a fixed number of MFMA pairs AHEAD of their use, one ds_read2st64 behind every pair:
+        // in the plain form the compiler reads eight values, waits, issues their eight MFMAs and only then reads the next eight -
+        // the matrix pipe runs dry for an LDS round trip after every batch unless the SIMD's other wave has MFMAs ready.  The
+        // compiler's scheduler regroups such reads whatever the source order (and sched_group_barrier only fixes the classes),
+        // so the reads and their counted waits are written as asm; the MFMAs hang on the waits through the register operands.
+        constexpr int BD = SPRL_WINO_BROLL;
+        static_assert(BD >= 1 && BD <= 8, "pairs in flight");
+        const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(vg + lane);
+        f2 bq[BD];
+#define SPRL_BREAD(dst, pr) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(vaddr), "n"(2 * (pr)), "n"(2 * (pr) + 1))
+#define SPRL_BPRE(pr) if constexpr ((pr) < BD) SPRL_BREAD(bq[(pr) % BD], (pr));
+#define SPRL_BMFMA(p, bv)                                                                                                              \
+        if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(p) >> 2][(p) & 3], bv, (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);         \
+        else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(p) >> 2][(p) & 3], bv, acc[p], 0, 0, 0);
+        // pair pr: wait until only the reads younger than this pair's are outstanding, two MFMAs, the read of pair pr + BD
+#define SPRL_BSTEP(pr)                                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[(pr) % BD]) : "n"((17 - (pr)) < (BD - 1) ? (17 - (pr)) : (BD - 1)));          \
+        SPRL_BMFMA(2 * (pr), bq[(pr) % BD][0])                                                                                        \
+        SPRL_BMFMA(2 * (pr) + 1, bq[(pr) % BD][1])                                                                                    \
+        if constexpr ((pr) + BD < 18) SPRL_BREAD(bq[(pr) % BD], (pr) + BD);                                                           \
+        if (((pr) & 1) && s + 1 < 16 && !LAB_OFF(6)) aload(s + 1, (pr) >> 1);
+        SPRL_BPRE(0) SPRL_BPRE(1) SPRL_BPRE(2) SPRL_BPRE(3) SPRL_BPRE(4) SPRL_BPRE(5) SPRL_BPRE(6) SPRL_BPRE(7)
+        SPRL_BSTEP(0) SPRL_BSTEP(1) SPRL_BSTEP(2) SPRL_BSTEP(3) SPRL_BSTEP(4) SPRL_BSTEP(5) SPRL_BSTEP(6) SPRL_BSTEP(7) SPRL_BSTEP(8)
+        SPRL_BSTEP(9) SPRL_BSTEP(10) SPRL_BSTEP(11) SPRL_BSTEP(12) SPRL_BSTEP(13) SPRL_BSTEP(14) SPRL_BSTEP(15) SPRL_BSTEP(16) SPRL_BSTEP(17)
+#undef SPRL_BSTEP
+#undef SPRL_BMFMA
+#undef SPRL_BPRE
+#undef SPRL_BREAD
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+#endif
 #pragma unroll
         for (int q4 = 0; q4 < 9; ++q4) {
 #pragma unroll
@@ -311,11 +431,13 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     auto rload = [&](int r) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, 2));
+            rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, SPRL_WINO_LD_AUX));
     };
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * V_G2;
+        LAB_STAMP_LATER(st0_);                         // phase start
         if (c + 2 < 8) lstore_from(in_buf + (c & 1) * IN_BUF2, pre);      // chunk c+2 -> in_buf[c & 1] (V(c) was built in phase c-1)
+        LAB_STAMP_LATER(st1_);                         // activation chunk stored (it had to arrive)
         // the first residual rows are requested before the LAST K step: the activation registers are dead, no filter quad is
         // requested behind them any more (nothing the K loop waits for queues up behind these HBM loads), and the output stage
         // finds them there one K step later
@@ -325,10 +447,20 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
             rload(0);
             rload(1);
         }
-        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{});
+        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{}, std::true_type{});
+        LAB_STAMP_LATER(st2_);                         // K step 2c+1 issued
         if (c + 1 < 8) produce(c + 1);
+        LAB_STAMP_LATER(st3_);                         // V(c+1) written
         __syncthreads();
-        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G2, 2 * c + 2, -1, std::false_type{});
+        LAB_STAMP_LATER(st4_);                         // barrier passed
+        if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * V_G2, 2 * c + 2, -1, std::false_type{}, std::false_type{});
+        LAB_STAMP_LATER(st5_);                         // K step 2c+2 issued
+        LAB_STAMP_WRITE(4 + 6 * c, st0_);
+        LAB_STAMP_WRITE(5 + 6 * c, st1_);
+        LAB_STAMP_WRITE(6 + 6 * c, st2_);
+        LAB_STAMP_WRITE(7 + 6 * c, st3_);
+        LAB_STAMP_WRITE(8 + 6 * c, st4_);
+        LAB_STAMP_WRITE(9 + 6 * c, st5_);
     };
 
     if constexpr (STEM) {
@@ -412,10 +544,13 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         lstore_from(in_buf + IN_BUF2, pre);
     }
     gload_to(2, pre);
+    LAB_STAMP(1);                                      // first chunks arrived and stored
     __syncthreads();
     produce(0);
     __syncthreads();
-    kstep(v_buf, 0, -1, std::true_type{});
+    LAB_STAMP(2);                                      // first V built
+    kstep(v_buf, 0, -1, std::true_type{}, std::false_type{});
+    LAB_STAMP(3);
     for (int c = 0; c < 8; ++c) phase(c);             // stays a rolled loop: peeled or fully unrolled forms measured 5 % slower
 
     // ---- inverse transform in registers + epilogue ----
@@ -473,11 +608,12 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hp[HEADS ? oc : 0][i][j] += hwk[oc] * v[j];
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * 1024 + i * 256), 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * 1024 + i * 256), 0, SPRL_WINO_ST_AUX);
             }
         }
         if (RES && r + 2 < 4) rload(r + 2);
     }
+    LAB_STAMP(52);                                     // output stage issued
     if (!HEADS) return;
 
     // ---- head convolutions fused behind the LAST trunk convolution: only the ReLU'd head maps are written ----
@@ -963,6 +1099,37 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         constexpr bool FIRST = decltype(first)::value;
         constexpr int AHEAD = DEEP ? 2 : 1;
         if (!FIRST && LAB_OFF(3)) return;              // lab: only the first K step (no MFMA loop)
+        constexpr int BD = M == 4 ? SPRL_WINO_BROLL_F4 : SPRL_WINO_BROLL_F3;
+        if constexpr (BD > 0) {   // rolling B-operand prefetch, as in the 8x8 kernel's K step (see there); NP = 25: the last "pair" is one position
+            constexpr int NPR = (NP + 1) / 2;
+            const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(vg + lane);
+            f2 bq[BD];
+#define SPRL_BREAD(dst, pr)                                                                                                            \
+            if constexpr (2 * (pr) + 1 < NP) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(vaddr), "n"(2 * (pr)), "n"(2 * (pr) + 1)); \
+            else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(vaddr), "n"(2 * (pr) * 256));
+#define SPRL_BPRE(pr) if constexpr ((pr) < BD && (pr) < NPR) { SPRL_BREAD(bq[(pr) % BD], (pr)) }
+#define SPRL_BMFMA(p, bv)                                                                                                              \
+            if constexpr ((p) < NP) {                                                                                                  \
+                if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(p) >> 2][(p) & 3], bv, (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0); \
+                else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(p) >> 2][(p) & 3], bv, acc[p], 0, 0, 0);                         \
+            }
+#define SPRL_BSTEP(pr)                                                                                                                 \
+            if constexpr ((pr) < NPR) {                                                                                                \
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[(pr) % BD]) : "n"((NPR - 1 - (pr)) < (BD - 1) ? (NPR - 1 - (pr)) : (BD - 1))); \
+                SPRL_BMFMA(2 * (pr), bq[(pr) % BD][0])                                                                                \
+                SPRL_BMFMA(2 * (pr) + 1, bq[(pr) % BD][1])                                                                            \
+                if constexpr ((pr) + BD < NPR) { SPRL_BREAD(bq[(pr) % BD], (pr) + BD) }                                               \
+                if ((((pr) & 1) || 2 * (pr) + 2 >= NP) && s + AHEAD < 16) aload(s + AHEAD, (pr) >> 1, a);                             \
+            }
+            SPRL_BPRE(0) SPRL_BPRE(1) SPRL_BPRE(2) SPRL_BPRE(3) SPRL_BPRE(4) SPRL_BPRE(5) SPRL_BPRE(6) SPRL_BPRE(7)
+            SPRL_BSTEP(0) SPRL_BSTEP(1) SPRL_BSTEP(2) SPRL_BSTEP(3) SPRL_BSTEP(4) SPRL_BSTEP(5) SPRL_BSTEP(6) SPRL_BSTEP(7) SPRL_BSTEP(8)
+            SPRL_BSTEP(9) SPRL_BSTEP(10) SPRL_BSTEP(11) SPRL_BSTEP(12) SPRL_BSTEP(13) SPRL_BSTEP(14) SPRL_BSTEP(15) SPRL_BSTEP(16) SPRL_BSTEP(17)
+#undef SPRL_BSTEP
+#undef SPRL_BMFMA
+#undef SPRL_BPRE
+#undef SPRL_BREAD
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
 #pragma unroll
@@ -1298,6 +1465,14 @@ extern "C" int sprl_wino_conv64_nchw(const float* x, const float* u, const float
     return sprl_wino_conv64_nchw_tiled(x, u, scale, shift, res, y, batch, H, W, relu, 4, nullptr, stream);
 }
 
+#ifdef SPRL_WINO_STAMPS
+extern "C" int sprl_wino_lab_set_trace(unsigned long long* trace, int first, int count) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(wino_lab_trace), &trace, sizeof(trace)) == hipSuccess &&
+                   hipMemcpyToSymbol(HIP_SYMBOL(wino_lab_trace_first), &first, sizeof(int)) == hipSuccess &&
+                   hipMemcpyToSymbol(HIP_SYMBOL(wino_lab_trace_count), &count, sizeof(int)) == hipSuccess
+               ? 0 : -1;
+}
+#endif
 #ifdef SPRL_WINO_LAB
 extern "C" int sprl_wino_lab_set_dbg(int mask) { return hipMemcpyToSymbol(HIP_SYMBOL(wino_lab_dbg), &mask, sizeof(int)) == hipSuccess ? 0 : -1; }
 #endif

@@ -53,6 +53,10 @@ def main():
     for name, mask, with_res in (("everything on", 0, True), ("no residual (RES = 0 variant)", 0, False),
                                  ("no input transform", 4, True), ("filter quads loaded once", 64, True),
                                  ("no output stage", 128, True),
+                                 ("no activation loads behind the prologue's", 1, True),
+                                 ("activation loads answered by L2 (every workgroup reads boards 0-3)", 256, True),
+                                 ("the same, without the residual", 256, False),
+                                 ("filters once + activation loads from L2", 64 + 256, True),
                                  ("no transform + filters once + no output stage (MFMA loop + activation loads)", 4 + 64 + 128, True)):
         L.sprl_wino_lab_set_dbg(mask)
         us = timeit(with_res)
