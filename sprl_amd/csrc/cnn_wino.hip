@@ -247,7 +247,9 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     }
 #endif
     LAB_STAMP(0);                                      // wave started
-    for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;    // borders stay zero for the whole kernel
+    // borders stay zero for the whole kernel.  (The fill BEHIND the first requests of the prologue - on their way to HBM while the 28
+    // LDS stores per thread are issued - was measured: 1.1 ... 1.6 % slower, profiles/r04zw_conv_ab_fill_behind_requests.log.)
+    for (int i = tid; i < 2 * IN_BUF2; i += NTHR2) lds[i] = 0.0f;
 
     int ldst[2], xvoff[2];                            // LDS float index / global byte offset of this thread's two 16-byte pieces of a chunk
 #pragma unroll
