@@ -145,6 +145,9 @@ constexpr int FC_MAXA = 96, FC_LP = 32;
 #ifndef SPRL_WINO_ST_AUX
 #define SPRL_WINO_ST_AUX 2                            // ... and of its output stores (default policy for either: -1.3 / -2.9 % in the bench, profiles/r04zo_*)
 #endif
+#ifndef SPRL_WINO_F4_REQ_HEAD
+#define SPRL_WINO_F4_REQ_HEAD 0                       // F(4x4) any-board kernel: the activation request at the head of the phase (0: behind the transform)
+#endif
 #ifndef SPRL_WINO_GLOAD_BRANCH
 #define SPRL_WINO_GLOAD_BRANCH 0                      // lab: 1 = the activation request of a phase sits behind a branch (the round-3 form)
 #endif
@@ -975,7 +978,11 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
         if constexpr (LAY == 1) {
 #pragma unroll
             for (int e = 0; e < NPC; ++e) {
-                const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, ld_toff[e], chunk * (2 * MC * 16) * TT, 0));
+                // chunk < 0: nothing left to request - the loads are issued all the same, with offsets the range check rejects (no
+                // memory access).  A branch around them would cost more: the compiler's wait counts must hold on both of its paths,
+                // so the `vmcnt(n)` of the next K step come out NPC too small on the path that did issue the loads, and its last
+                // filter quads wait for the HBM trip of the activation chunk (see the 8x8 kernel's gload_to).
+                const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, chunk < 0 ? OOB : ld_toff[e], (chunk < 0 ? 0 : chunk) * (2 * MC * 16) * TT, 0));
                 pre[4 * e] = v[0]; pre[4 * e + 1] = v[1]; pre[4 * e + 2] = v[2]; pre[4 * e + 3] = v[3];
             }
             return;
@@ -1162,16 +1169,27 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
                 rv0[cc] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, obase + cc * TT * 16, 0, 0));
         }
     };
+    // REQ_HEAD (layout T, one chunk in flight = F(4x4)): chunk c+2 goes to LDS and chunk c+3 is requested at the HEAD of the phase,
+    // in front of K step 2c+1, as the 8x8 kernel does - loads return in issue order, so the filter quads requested behind an
+    // activation request wait for its trip to HBM; from the head of the phase that trip has K step 2c+1 and the transform to
+    // complete before K step 2c+2 asks for its quads, from its old place behind the transform only the barrier.
+    constexpr bool REQ_HEAD = LAY == 1 && !DEEP_ACT && SPRL_WINO_F4_REQ_HEAD;
     auto phase = [&](int c, float* pre) {
         const float* vs = v_buf + (c & 1) * 2 * VG;
         if (EARLY_RES && !DEEP && c == 7) early_res();
+        if constexpr (REQ_HEAD) {
+            if (c + 2 < 8) lstore(in_buf + (c & 1) * IN_BUF, pre);
+            gload(c + 3 < 8 ? c + 3 : -1, pre);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         kstep(vs + VG, 2 * c + 1, std::false_type{}, DEEP ? a1 : a0);
         __builtin_amdgcn_sched_barrier(0);
         if (EARLY_RES && DEEP && c == 6) early_res();
         if (c + 1 < 8) produce(c + 1);
-        if (c + 2 < 8) {
-            lstore(in_buf + (c & 1) * IN_BUF, pre);
-            if (c + (DEEP_ACT ? 4 : 3) < 8) gload(c + (DEEP_ACT ? 4 : 3), pre);
+        if constexpr (!REQ_HEAD) {
+            if (c + 2 < 8) lstore(in_buf + (c & 1) * IN_BUF, pre);
+            if (LAY == 1 && !SPRL_WINO_GLOAD_BRANCH) gload(c + (DEEP_ACT ? 4 : 3) < 8 ? c + (DEEP_ACT ? 4 : 3) : -1, pre);      // unconditional (see gload)
+            else if (c + (DEEP_ACT ? 4 : 3) < 8) gload(c + (DEEP_ACT ? 4 : 3), pre);
         }
         __syncthreads();
         if (c + 1 < 8) kstep(v_buf + ((c + 1) & 1) * 2 * VG, 2 * c + 2, std::false_type{}, a0);
