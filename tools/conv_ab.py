@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--shapes", nargs="+", default=["8x8", "go9", "go19"])
     ap.add_argument("--boards", type=int, nargs="+", default=None)
     ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--rounds", type=int, default=4)
     a = ap.parse_args()
     if a.build:
         build(a.build)
@@ -119,9 +119,10 @@ def main():
             same = {t: bool((ys[t].view(torch.int32) == ref.view(torch.int32)).all()) for t in libs}
             err = err_of(ref) if with_res else float("nan")
             best = {t: 1e30 for t in libs}
-            for _ in range(a.rounds):                    # alternate the builds: clock drift hits all of them alike
-                for t in libs:
-                    for _ in range(3):
+            order = list(libs)
+            for rnd in range(a.rounds):                  # alternate the builds, another one first in every round: the build that is
+                for t in order[rnd % len(order):] + order[:rnd % len(order)]:      # timed first after a pause comes out 1-4 % slow
+                    for _ in range(10):
                         run(t, with_res)
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
