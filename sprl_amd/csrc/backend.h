@@ -28,6 +28,13 @@ void stream_destroy(void* s);
 void set_stream(void* s);
 void bind(int device, void* s);   // make `device` current on the calling thread and `s` its stream
 void* current_stream();
+// lab (SPRL_TREE_STREAM): a second stream per engine for the tree / scan / gather launches, at the highest priority the device
+// offers when `high`, tied to the engine's stream by two re-recorded events
+void* stream_create_priority(int high);
+void* event_new();
+void event_free(void* ev);
+void event_record(void* ev, void* stream);
+void stream_wait(void* stream, void* ev);
 // one 64-lane wavefront per game slot, on the null stream
 int launch_step(int game, const EngineParams& P);
 // match play: slots (pair, pair + num_slots/2) hold the two agents' trees of one game; Othello, Connect Four, Go 7x7

@@ -194,6 +194,22 @@ void* stream_create() {
     if (!ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
     return (void*)s;
 }
+void* stream_create_priority(int high) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);      // numerically lower = higher priority
+    hipStream_t s = nullptr;
+    if (!ok(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least), "hipStreamCreateWithPriority")) return nullptr;
+    return (void*)s;
+}
+void* event_new() {
+    hipEvent_t e = nullptr;
+    return ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate") ? (void*)e : nullptr;
+}
+void event_free(void* ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+void event_record(void* ev, void* stream) { (void)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+void stream_wait(void* stream, void* ev) { (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0); }
 void stream_destroy(void* s) {
     if (s) (void)hipStreamDestroy((hipStream_t)s);
 }

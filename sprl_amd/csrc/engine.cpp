@@ -131,6 +131,10 @@ struct sprl_engine {
     // sprl_engine_evaluator_info: SPRL_SYNC_ROUNDS (host reads the leaf count every round), SPRL_GO_LEGAL (legal-move algorithm)
     bool lab_sync_rounds = false;
     std::string lab;           // the names that were set, "" = defaults
+    // lab, SPRL_TREE_STREAM=1|2: the tree / scan / gather launches of a round go to a second stream of the
+    // engine (2: at the device's highest priority), the forward stays on `stream`; ev_tree / ev_fwd order the two every round
+    void* tree_stream = nullptr;
+    void *ev_tree = nullptr, *ev_fwd = nullptr;
 };
 
 namespace {
@@ -361,6 +365,19 @@ int sprl_engine_create(const sprl_config* cfg, sprl_engine** out) {
         e->lab_sync_rounds = true;
         e->lab += std::string(e->lab.empty() ? "" : " ") + "SPRL_SYNC_ROUNDS";
     }
+    if (const char* f = getenv("SPRL_TREE_STREAM")) {
+        if (e->stream && (f[0] == '1' || f[0] == '2')) {
+            e->tree_stream = be::stream_create_priority(f[0] == '2');
+            e->ev_tree = be::event_new();
+            e->ev_fwd = be::event_new();
+            if (!e->tree_stream || !e->ev_tree || !e->ev_fwd) {
+                std::string why = be::last_error();
+                sprl_engine_destroy(e);
+                return fail(SPRL_E_DEVICE, "SPRL_TREE_STREAM: cannot create the second stream (" + why + ")");
+            }
+            e->lab += std::string(e->lab.empty() ? "" : " ") + "SPRL_TREE_STREAM=" + f[0];
+        }
+    }
     P.resign_threshold = cfg->resign_threshold;
     P.resign_min_ply = cfg->resign_min_ply;
     P.use_sym = cfg->use_symmetry ? 1 : 0;
@@ -444,6 +461,9 @@ void sprl_engine_destroy(sprl_engine* e) {
     be::chain_free(e->chain);
     if (e->torch_model && e->torch.release) e->torch.release(e->torch_model);
     for (void* p : e->allocs) be::dfree(p);
+    if (e->tree_stream) be::stream_destroy(e->tree_stream);
+    be::event_free(e->ev_tree);
+    be::event_free(e->ev_fwd);
     if (e->stream) be::stream_destroy(e->stream);
     be::set_stream(nullptr);
     delete e;
@@ -602,10 +622,16 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
     const int floats_per_leaf = e->g.planes * e->g.cells;
     Counters c;
     memset(&c, 0, sizeof(c));
+    const bool split = net && e->tree_stream;             // lab: tree / scan / gather on the engine's second stream
+    if (split) be::event_record(e->ev_fwd, e->stream);     // (everything issued so far on the engine's stream comes first)
     for (int r = 0; r < launches; ++r) {
         // network rounds: the leaf scan behind the step kernel moves active_slots to active_last and clears it (one launch less
         // per round); the chained rounds of the in-kernel evaluators have no scan
         if (!net) be::dmemset(&P.counters->active_slots, 0, sizeof(uint32_t));
+        if (split) {
+            be::stream_wait(e->tree_stream, e->ev_fwd);   // the answers of the previous round's forward
+            be::set_stream(e->tree_stream);
+        }
         void* k0 = e->cfg.profile ? be::mark() : nullptr;
         if (be::launch_step(e->cfg.game, P) != 0) return fail(SPRL_E_DEVICE, be::last_error());
         if (e->cfg.profile) {
@@ -618,6 +644,11 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
             // dense batch: only the leaves that were really queued, slot-major (deterministic), in buckets of
             // `bucket` rows so the convolution library sees a handful of shapes
             if (be::launch_compact(P, floats_per_leaf) != 0) return fail(SPRL_E_DEVICE, be::last_error());
+            if (split) {
+                be::event_record(e->ev_tree, e->tree_stream);
+                be::set_stream(e->stream);
+                be::stream_wait(e->stream, e->ev_tree);    // the forward (and everything else on the engine's stream) behind the gather
+            }
             if (e->dev_batch && !e->forward_cb) {
                 // the evaluator reads the leaf count from the device: no host round trip between rounds; completion and
                 // errors are looked at every 8 rounds (rounds after the last game ended find nothing to do)
@@ -637,6 +668,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
                     e->mark_kind.push_back(1);
                 }
                 e->nn_batches++;
+                if (split) be::event_record(e->ev_fwd, e->stream);
                 if ((r & 7) == 7 || r == launches - 1) {
                     if (be::sync() != 0 || be::d2h(&c, P.counters, sizeof(c)) != 0) return fail(SPRL_E_DEVICE, be::last_error());
                     c.active_slots = c.active_last;
@@ -679,6 +711,7 @@ int sprl_engine_step(sprl_engine* e, int32_t rounds, int32_t* games_done, int32_
                     e->mark_kind.push_back(1);
                 }
                 e->nn_batches++;
+                if (split) be::event_record(e->ev_fwd, e->stream);
                 e->nn_rows += batch;
             }
             if (c.games_done >= (uint32_t)e->num_games && c.active_slots == 0 && c.leaf_total == 0) break;

@@ -94,7 +94,12 @@ int d2h(void* dst, const void* src, size_t n) { memcpy(dst, src, n); return 0; }
 int dmemset(void* dst, int v, size_t n) { memset(dst, v, n); return 0; }
 int sync() { return 0; }
 static int g_stream_token;                       // own_stream on the emulator: kernels run synchronously on the calling thread, a
-void* stream_create() { return &g_stream_token; }   // "stream" is just a non-null token (engines on different host threads are independent)
+void* stream_create() { return &g_stream_token; }
+void* stream_create_priority(int) { return &g_stream_token; }      // (launches are synchronous here: events and waits are no-ops)
+void* event_new() { return &g_stream_token; }
+void event_free(void*) {}
+void event_record(void*, void*) {}
+void stream_wait(void*, void*) {}   // "stream" is just a non-null token (engines on different host threads are independent)
 void stream_destroy(void*) {}
 void set_stream(void*) {}
 void bind(int, void*) {}

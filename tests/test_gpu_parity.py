@@ -555,6 +555,15 @@ def test_wide_board_forward_on_device_count_equals_host_count(lib, tmp_path, mon
     assert (dev[0][0] == host[0][0]).all() and (dev[0][1] == host[0][1]).all() and (dev[2] == host[2]).all()
     assert (dev[1].view(np.uint32) == host[1].view(np.uint32)).all()
     assert dev[4]["nn_evals"] == host[4]["nn_evals"] and dev[4]["nn_evals"] > 0
+    if game == "go9":
+        # lab switch SPRL_TREE_STREAM (measured and left off): tree / scan / gather launches on a
+        # second, high-priority stream of the engine, ordered against the forward by two events - the same games, bit for bit
+        monkeypatch.setenv("SPRL_TREE_STREAM", "2")
+        split = play()
+        monkeypatch.delenv("SPRL_TREE_STREAM")
+        assert "SPRL_TREE_STREAM=2" in split[3], split[3]
+        assert (dev[0][0] == split[0][0]).all() and (dev[0][1] == split[0][1]).all() and (dev[2] == split[2]).all()
+        assert (dev[1].view(np.uint32) == split[1].view(np.uint32)).all() and dev[4]["nn_evals"] == split[4]["nn_evals"]
 
 
 def test_go9_plugin_forward_matches_torchscript(lib, tmp_path):
