@@ -537,8 +537,8 @@ def test_wide_board_forward_on_device_count_equals_host_count(lib, tmp_path, mon
     from sprl_amd.network import make_network, trace_to_file
     model = trace_to_file(make_network(game, 2, 64, seed=8), str(tmp_path / f"traced_{game}_dev.pt"), game)
 
-    def play():
-        cfg = E.default_config(game, lib, concurrent_games=games, num_traversals=trav, seed=4)
+    def play(own_stream=0):
+        cfg = E.default_config(game, lib, concurrent_games=games, num_traversals=trav, seed=4, own_stream=own_stream)
         eng = E.Engine(cfg, lib)
         eng.set_model(model)
         info = eng.evaluator_info()
@@ -559,7 +559,7 @@ def test_wide_board_forward_on_device_count_equals_host_count(lib, tmp_path, mon
         # lab switch SPRL_TREE_STREAM (measured and left off): tree / scan / gather launches on a
         # second, high-priority stream of the engine, ordered against the forward by two events - the same games, bit for bit
         monkeypatch.setenv("SPRL_TREE_STREAM", "2")
-        split = play()
+        split = play(own_stream=1)                          # (the switch needs an engine with a stream of its own)
         monkeypatch.delenv("SPRL_TREE_STREAM")
         assert "SPRL_TREE_STREAM=2" in split[3], split[3]
         assert (dev[0][0] == split[0][0]).all() and (dev[0][1] == split[0][1]).all() and (dev[2] == split[2]).all()
