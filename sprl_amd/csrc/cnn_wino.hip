@@ -148,6 +148,9 @@ constexpr int FC_MAXA = 96, FC_LP = 32;
 #ifndef SPRL_WINO_F4_REQ_HEAD
 #define SPRL_WINO_F4_REQ_HEAD 0                       // F(4x4) any-board kernel: the activation request at the head of the phase (0: behind the transform)
 #endif
+#ifndef SPRL_WINO_REQ_POS
+#define SPRL_WINO_REQ_POS 0                           // 8x8 kernel: the activation request at the head (0) / middle (1) / end (2) of K step 2c+1
+#endif
 #ifndef SPRL_WINO_GLOAD_BRANCH
 #define SPRL_WINO_GLOAD_BRANCH 0                      // lab: 1 = the activation request of a phase sits behind a branch (the round-3 form)
 #endif
@@ -182,7 +185,8 @@ __constant__ int wino_lab_dbg;
 #if defined(SPRL_WINO_LAB) || defined(SPRL_WINO_TRACE)
 // timeline (tools/wino8_trace.py, a build with -DSPRL_WINO_TRACE: the product kernel plus the stamps): lane 0 of every wave of the
 // workgroups [first, first + count) writes the shader clock at the marked points of the 8x8 kernel to
-// trace[(block - first) * 4 + wave][0..63]; stamp 63 is the wave's HW_ID (CU / SIMD / wave slot), 62 its XCC_ID.
+// trace[(block - first) * 4 + wave][0..127]; stamp 63 is the wave's HW_ID (CU / SIMD / wave slot), 62 its XCC_ID; 64 + 2c, 65 + 2c: inside
+// K step 2c+1 (behind the activation request, behind its fifth filter quad).
 // (`tracing` / `trace_row` are set once at the top of the kernel; the stamps of a phase wait in scalar registers and are written
 // together at its end, so that a traced wave pays one wait for the clock reads per phase)
 #define SPRL_WINO_STAMPS 1
@@ -242,8 +246,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
 
 #ifdef SPRL_WINO_STAMPS
     const bool tracing = wino_lab_trace && (int)blockIdx.x >= wino_lab_trace_first && (int)blockIdx.x < wino_lab_trace_first + wino_lab_trace_count;
-    unsigned long long* const trace_row = wino_lab_trace + (((int)blockIdx.x - wino_lab_trace_first) * 4 + wave) * 64;
-    unsigned long long st0_ = 0, st1_ = 0, st2_ = 0, st3_ = 0, st4_ = 0, st5_ = 0;
+    unsigned long long* const trace_row = wino_lab_trace + (((int)blockIdx.x - wino_lab_trace_first) * 4 + wave) * 128;
+    unsigned long long st0_ = 0, st1_ = 0, st2_ = 0, st3_ = 0, st4_ = 0, st5_ = 0, st6_ = 0, st7_ = 0;
     if (tracing && lane == 0) {
         trace_row[63] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_ID
         trace_row[62] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));      // XCC_ID
@@ -359,9 +363,10 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
 #if SPRL_WINO_GLOAD_BRANCH
         if (chunk >= 0) gload_to(chunk, pre);         // lab: the round-3 form
 #else
-        if (WITH_GLOAD) {                              // issued whether or not there is a chunk left to request (see gload_to)
+        if (WITH_GLOAD && SPRL_WINO_REQ_POS == 0) {    // issued whether or not there is a chunk left to request (see gload_to)
             gload_to(chunk, pre);
             __builtin_amdgcn_sched_barrier(0);         // at the HEAD of the K step: as far ahead of the filter quads requested behind it as it gets
+            LAB_STAMP_LATER(st6_);                     // request issued
         }
 #endif
 #if SPRL_WINO_BROLL
@@ -410,6 +415,17 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
                 else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], bv, acc[p], 0, 0, 0);
             }
             if (s + 1 < 16 && !LAB_OFF(6)) aload(s + 1, q4);     // (lab bit 6: the filter quads are loaded once and reused)
+            if (WITH_GLOAD && ((SPRL_WINO_REQ_POS == 1 && q4 == 4) || (SPRL_WINO_REQ_POS == 2 && q4 == 8))) {
+                __builtin_amdgcn_sched_barrier(0);     // lab: the request in the middle / at the end of the K step
+                gload_to(chunk, pre);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef SPRL_WINO_STAMPS
+            if (WITH_GLOAD && q4 == 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                LAB_STAMP_LATER(st7_);                 // five of the nine filter quads of the K step consumed
+            }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -466,6 +482,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         LAB_STAMP_WRITE(7 + 6 * c, st3_);
         LAB_STAMP_WRITE(8 + 6 * c, st4_);
         LAB_STAMP_WRITE(9 + 6 * c, st5_);
+        LAB_STAMP_WRITE(64 + 2 * c, st6_);
+        LAB_STAMP_WRITE(65 + 2 * c, st7_);
     };
 
     if constexpr (STEM) {

@@ -53,7 +53,7 @@ def main():
     us_plain = e0.elapsed_time(e1) / 20 * 1e3
     groups = (B + 3) // 4
     first, count = min(a.first, max(groups - 1, 0)), min(a.count, groups - min(a.first, max(groups - 1, 0)))
-    trace = torch.zeros(count * 4 * 64, dtype=torch.int64, device="cuda")
+    trace = torch.zeros(count * 4 * 128, dtype=torch.int64, device="cuda")
     assert L.sprl_wino_lab_set_trace(trace.data_ptr(), first, count) == 0
     e0.record()
     run()
@@ -61,7 +61,7 @@ def main():
     torch.cuda.synchronize()
     us_traced = e0.elapsed_time(e1) * 1e3
     L.sprl_wino_lab_set_trace(None, 0, 0)
-    t = trace.cpu().numpy().reshape(count, 4, 64).astype(np.int64)
+    t = trace.cpu().numpy().reshape(count, 4, 128).astype(np.int64)
     t0 = t[:, :, 0].min()
     span = t[:, :, 52].max() - t0
     print(f"8x8 trunk convolution, {B} boards = {groups} workgroups, res={int(not a.no_res)}: {us_plain:.1f} us per launch "
@@ -82,6 +82,13 @@ def main():
     print("  phase segments, mean ticks per wave (phases 0..7):")
     for k in range(5):
         print(f"    {SEG[k]:18s} " + " ".join(f"{seg[:, :, c, k].mean():7.0f}" for c in range(8)) + f"   | mean of phases 1-6: {seg[:, :, 1:7, k].mean():7.0f}")
+    inner = np.zeros((count, 4, 8, 3), np.int64)          # K step 2c+1: request issue, first five quads, last four
+    for c in range(8):
+        inner[:, :, c, 0] = t[:, :, 64 + 2 * c] - t[:, :, 5 + 6 * c]
+        inner[:, :, c, 1] = t[:, :, 65 + 2 * c] - t[:, :, 64 + 2 * c]
+        inner[:, :, c, 2] = t[:, :, 6 + 6 * c] - t[:, :, 65 + 2 * c]
+    for k, name in enumerate(("  of it: request", "  quads 0-4", "  quads 5-8")):
+        print(f"    {name:18s} " + " ".join(f"{inner[:, :, c, k].mean():7.0f}" for c in range(8)))
     tot = seg[:, :, 1:7, :].sum(-1).mean()
     print(f"    one phase (1-6)    {tot:7.0f} ticks; MFMA issue needs 2 x 36 x 32 = 2304 cycles of the SIMD's matrix pipe per wave and phase")
     out = (t[:, :, 52] - t[:, :, 51]).mean()
