@@ -148,6 +148,9 @@ constexpr int FC_MAXA = 96, FC_LP = 32;
 #ifndef SPRL_WINO_F4_REQ_HEAD
 #define SPRL_WINO_F4_REQ_HEAD 0                       // F(4x4) any-board kernel: the activation request at the head of the phase (0: behind the transform)
 #endif
+#ifndef SPRL_WINO_WGROUP
+#define SPRL_WINO_WGROUP 0                            // lab: 8x8 kernel on a group-major activation layout (see xvoff)
+#endif
 #ifndef SPRL_WINO_REQ_POS
 #define SPRL_WINO_REQ_POS 0                           // 8x8 kernel: the activation request at the head (0) / middle (1) / end (2) of K step 2c+1
 #endif
@@ -265,7 +268,13 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         const int b = f >> 7, rem = f & 127;
         const int g2 = rem >> 6, i = (rem >> 4) & 3, cs = (rem >> 2) & 3, tile = rem & 3;
         ldst[it] = (g2 * 4 + cs) * CS2 + board_off(b) + (4 * (tile >> 1) + i + 1) * RS + 4 * (tile & 1) + 1;
+#if SPRL_WINO_WGROUP
+        // lab: layout W', group-major over the four boards of a workgroup - x[n / 4][g][n % 4][256] - so that a chunk of the workgroup
+        // (2 groups x 4 boards) is ONE contiguous 8 KB piece instead of four 2 KB pieces 16 KB apart (batch a multiple of 4)
+        xvoff[it] = (n0 * 4096 + g2 * 1024 + b * 256 + (rem & 63) * 4) * 4;
+#else
         xvoff[it] = ((n0 + b) * 4096 + rem * 4) * 4;  // the per-lane offset carries the board: the range check drops boards >= batch
+#endif
     }
     const int patch0 = (gl * 4 + c_sub) * CS2 + board_off(tl >> 2) + ((tl >> 1) & 1) * 4 * RS + (tl & 1) * 4 + wa * RS;
     const int vdst0 = gl * V_G2 + (3 * wa) * 6 * 64 + lane;
@@ -280,7 +289,11 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     // a 16-byte buffer store needs no wait state before its data registers are overwritten (LLVM createsVALUHazard: "hazard only
     // exists if the instruction is not using a register in the soffset field") and schedules a VALU write into them right behind
     // the store; on gfx950 that corrupted dword 1 of lanes 12-15 of every 16 (found with tools/wino_lab.hip).
+#if SPRL_WINO_WGROUP
+    const int ovoff = (n0 * 4096 + kb * 4096 + (tl >> 2) * 256 + c_sub * 16 + tile * 4) * 4;      // + r * 4096 + i * 256 bytes
+#else
     const int ovoff = ((n0 + (tl >> 2)) * 4096 + kb * 1024 + c_sub * 16 + tile * 4) * 4;
+#endif
 
     f4 acc[36];                                       // first written by the first K step (C operand = 0): no zero fill
     f4 pre[2];                                        // the activation chunk in flight
@@ -296,7 +309,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
             // the path that did issue them - and the last filter quads of the step then wait for the HBM trip of the activation
             // chunk itself (tools/conv_ab.py, profiles/r04zt_conv_ab_request_without_branch.log: +0.2 ... +2.7 %).
             if (chunk < 0) voff = (int)0x80000000;
-            dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (chunk < 0 ? 0 : chunk) * 2048, SPRL_WINO_LD_AUX));
+            dst[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (chunk < 0 ? 0 : chunk) * (SPRL_WINO_WGROUP ? 8192 : 2048), SPRL_WINO_LD_AUX));
         }
     };
     auto lstore_from = [&](float* buf, const f4 (&src)[2]) {
@@ -452,7 +465,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     auto rload = [&](int r) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * 1024 + i * 256), 0, SPRL_WINO_LD_AUX));
+            rres[r][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rr, ovoff + (r * (SPRL_WINO_WGROUP ? 4096 : 1024) + i * 256), 0, SPRL_WINO_LD_AUX));
     };
     auto phase = [&](int c) {
         const float* vs = v_buf + (c & 1) * 2 * V_G2;
@@ -631,7 +644,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hp[HEADS ? oc : 0][i][j] += hwk[oc] * v[j];
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * 1024 + i * 256), 0, SPRL_WINO_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, ovoff + (r * (SPRL_WINO_WGROUP ? 4096 : 1024) + i * 256), 0, SPRL_WINO_ST_AUX);
             }
         }
         if (RES && r + 2 < 4) rload(r + 2);

@@ -34,7 +34,8 @@ def build(specs):
         subprocess.check_call(cmd)
 
 
-def shape_8x8(libs, B, iters):
+def shape_8x8(libs, B, iters, wgroup=()):
+    """wgroup: tags of builds with -DSPRL_WINO_WGROUP=1 (layout W' = [n / 4][g][n % 4][256]; B a multiple of 4)"""
     from tools.experiments.wino8_ab import from_layout_w, to_layout_w
     torch.manual_seed(2)
     xs, rs = torch.randn(B, 64, 8, 8, device="cuda"), torch.randn(B, 64, 8, 8, device="cuda")
@@ -44,11 +45,21 @@ def shape_8x8(libs, B, iters):
     sc, sh = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.3
     ys = {t: torch.empty_like(x) for t in libs}
 
+    def regroup(t):                                       # [B][16 g][256] -> [B / 4][16 g][4][256]
+        return t.view(B // 4, 4, 16, 256).permute(0, 2, 1, 3).contiguous().view(B, 4096)
+
+    def ungroup(t):
+        return t.view(B // 4, 16, 4, 256).permute(0, 2, 1, 3).contiguous().view(B, 4096)
+
+    xg, resg = (regroup(x), regroup(res)) if wgroup else (None, None)
+
     def run(tag, with_res):
         L = libs[tag]
-        return L.sprl_wino_conv64(x.data_ptr(), u.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr() if with_res else None,
+        xi, ri = (xg, resg) if tag in wgroup else (x, res)
+        return L.sprl_wino_conv64(xi.data_ptr(), u.data_ptr(), sc.data_ptr(), sh.data_ptr(), ri.data_ptr() if with_res else None,
                                   ys[tag].data_ptr(), B, 8, 8, 1, None)
 
+    run.post = {t: ungroup for t in wgroup}                # outputs of these builds come back in layout W'
     nb = min(B, 64)
     want = torch.relu(torch.nn.functional.conv2d(xs[-nb:].double(), w.double().cuda(), padding=1) * sc.double().view(1, -1, 1, 1)
                       + sh.double().view(1, -1, 1, 1) + rs[-nb:].double())
@@ -89,6 +100,7 @@ def main():
     ap.add_argument("--shapes", nargs="+", default=["8x8", "go9", "go19"])
     ap.add_argument("--boards", type=int, nargs="+", default=None)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--wgroup", nargs="*", default=[], help="tags built with -DSPRL_WINO_WGROUP=1 (8x8 only; fed the group-major layout)")
     ap.add_argument("--rounds", type=int, default=4)
     a = ap.parse_args()
     if a.build:
@@ -108,7 +120,11 @@ def main():
     default_boards = {"8x8": 13492, "go9": 8192, "go19": 2048}
     for i, shape in enumerate(a.shapes):
         B = a.boards[i] if a.boards and i < len(a.boards) else default_boards[shape]
-        run, ys, err_of, flop, title = shape_8x8(libs, B, a.iters) if shape == "8x8" else shape_go(shape, libs, B, a.iters)
+        if shape == "8x8":
+            B -= B % 4 if a.wgroup else 0
+            run, ys, err_of, flop, title = shape_8x8(libs, B, a.iters, tuple(a.wgroup))
+        else:
+            run, ys, err_of, flop, title = shape_go(shape, libs, B, a.iters)
         print(title, flush=True)
         for with_res in (True, False):
             for t in libs:
@@ -116,7 +132,8 @@ def main():
                 assert run(t, with_res) == 0
             torch.cuda.synchronize()
             ref = ys[a.run[0]]
-            same = {t: bool((ys[t].view(torch.int32) == ref.view(torch.int32)).all()) for t in libs}
+            post = getattr(run, "post", {})
+            same = {t: bool(((post[t](ys[t]) if t in post else ys[t]).view(torch.int32) == ref.view(torch.int32)).all()) for t in libs}
             err = err_of(ref) if with_res else float("nan")
             best = {t: 1e30 for t in libs}
             order = list(libs)
