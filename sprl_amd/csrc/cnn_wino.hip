@@ -303,6 +303,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
             if (LAB_OFF(0) && chunk > 2) continue;     // lab: no activation loads behind the prologue's
             // (lab bit 8: every workgroup reads the first four boards - the same stream of requests, answered by L2 instead of HBM)
             int voff = LAB_OFF(8) ? xvoff[it] - n0 * 16384 : xvoff[it];
+            // (lab bit 9: the boards of a 64 MB window - too large for the L2s, small enough for the memory-side cache)
+            if (LAB_OFF(9)) voff = xvoff[it] - (n0 - n0 % 4096) * 16384;
             // chunk < 0 = "nothing to request": the load is issued all the same, with an offset the range check rejects (no memory
             // access, zeros come back at once).  A BRANCH around the loads costs more than the loads: the compiler's wait counts
             // must hold on both paths, so behind a skipped-or-not pair of loads every `vmcnt(n)` of the K step is two too small on

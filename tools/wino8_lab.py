@@ -56,6 +56,8 @@ def main():
                                  ("no activation loads behind the prologue's", 1, True),
                                  ("activation loads answered by L2 (every workgroup reads boards 0-3)", 256, True),
                                  ("the same, without the residual", 256, False),
+                                 ("activation loads from a 64 MB window (memory-side cache, not L2)", 512, True),
+                                 ("the same, without the residual", 512, False),
                                  ("filters once + activation loads from L2", 64 + 256, True),
                                  ("no transform + filters once + no output stage (MFMA loop + activation loads)", 4 + 64 + 128, True)):
         L.sprl_wino_lab_set_dbg(mask)
