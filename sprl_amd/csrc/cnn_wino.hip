@@ -148,6 +148,13 @@ constexpr int FC_MAXA = 96, FC_LP = 32;
 #ifndef SPRL_WINO_F4_REQ_HEAD
 #define SPRL_WINO_F4_REQ_HEAD 0                       // F(4x4) any-board kernel: the activation request at the head of the phase (0: behind the transform)
 #endif
+// 8x8 kernel: n > 0 = the input transform of chunk c+1 is issued in six pieces behind filter quads n-1 .. n+4 of K step 2c+1 (under the
+// wave's own MFMAs) instead of as one block between the K steps.  Together with the rolling B reads (SPRL_WINO_BROLL = 4; without
+// them every piece cuts the K step's LDS reads off from their MFMAs: -1 ... -2 %): lab +0.2 ... +2.8 %, bench 455.3 / 456.0 against
+// 451.8 / 451.4 games/s in one call (profiles/r04zzm_*, r04zzn_*).  0 = the round-3 form.
+#ifndef SPRL_WINO_INTERLEAVE
+#define SPRL_WINO_INTERLEAVE 1
+#endif
 #ifndef SPRL_WINO_WGROUP
 #define SPRL_WINO_WGROUP 0                            // lab: 8x8 kernel on a group-major activation layout (see xvoff)
 #endif
@@ -164,11 +171,11 @@ constexpr int FC_MAXA = 96, FC_LP = 32;
 #define SPRL_WINO_PRIO_LEVEL 1
 #endif
 // B operands of a K step (V from LDS) read a fixed number of MFMA pairs AHEAD of their use (rolling, asm reads with counted waits:
-// see the K step of the 8x8 kernel).  Measured per kernel (tools/conv_ab.py, profiles/r04zl_conv_ab_broll.log): the F(4x4) any-board
-// kernel gains 4 % (19x19), the 8x8 kernel nothing (+-1 %: its SIMD's other wave already covers the LDS round trips) and the
-// F(3x3) kernel has no registers for it (61 spilled) - so it is on for F(4x4) only.  0 = the compiler's own batches of eight.
+// see the K step of the 8x8 kernel).  Measured per kernel (tools/conv_ab.py, profiles/r04zl_conv_ab_broll.log, r04zzb_*): the F(4x4)
+// any-board kernel gains 1.3 - 3.5 % (19x19), the 8x8 kernel nothing by itself (+-1 %: its SIMD's other wave already covers the LDS
+// round trips) and the F(3x3) kernel has no registers for it (61 spilled).  0 = the compiler's own batches of eight.
 #ifndef SPRL_WINO_BROLL
-#define SPRL_WINO_BROLL 0                             // 8x8 kernel
+#define SPRL_WINO_BROLL 4                             // 8x8 kernel (alone +-1 %; it is what makes the interleaved transform pay, see SPRL_WINO_INTERLEAVE)
 #endif
 #ifndef SPRL_WINO_BROLL_F4
 #define SPRL_WINO_BROLL_F4 4                          // any-board kernel, F(4x4,3x3)
@@ -364,6 +371,42 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
             vd[(r * 6 + 5) * 64] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
         }
     };
+#if SPRL_WINO_INTERLEAVE
+    // lab: the same transform in six PIECES (stage 1 per pair of columns, stage 2 per row) that K step 2c+1 issues between its filter
+    // quads - the wave's own MFMAs cover its transform, instead of the other wave of the SIMD having to
+    f2 wri[3][3];
+    auto produce_piece = [&](int c, auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value;
+        const float* pp = in_buf + (c & 1) * IN_BUF2 + patch0;
+        float* vd = v_buf + (c & 1) * 2 * V_G2 + vdst0;
+        if constexpr (piece < 3) {
+            constexpr int jp = piece, j = 2 * jp;
+            const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[RS + j], pp[RS + j + 1] }, e2 = { pp[2 * RS + j], pp[2 * RS + j + 1] },
+                     e3 = { pp[3 * RS + j], pp[3 * RS + j + 1] }, e4 = { pp[4 * RS + j], pp[4 * RS + j + 1] };
+            if (wa == 0) {
+                const f2 p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                wri[0][jp] = (4.0f * e0 + e4) - 5.0f * e2;
+                wri[1][jp] = p + q;
+                wri[2][jp] = p - q;
+            } else {
+                const f2 p = e3 - e1, d = e2 - e0;
+                wri[0][jp] = p + 2.0f * d;
+                wri[1][jp] = p - 2.0f * d;
+                wri[2][jp] = (4.0f * e0 + e4) - 5.0f * e2;
+            }
+        } else {
+            constexpr int r = piece - 3;
+            const float w0 = wri[r][0][0], w1 = wri[r][0][1], w2 = wri[r][1][0], w3 = wri[r][1][1], w4 = wri[r][2][0], w5 = wri[r][2][1];
+            const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3), p2 = w4 - w2, d2 = w3 - w1;
+            vd[(r * 6 + 0) * 64] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
+            vd[(r * 6 + 1) * 64] = p + q;
+            vd[(r * 6 + 2) * 64] = p - q;
+            vd[(r * 6 + 3) * 64] = __builtin_fmaf(2.0f, d2, p2);
+            vd[(r * 6 + 4) * 64] = __builtin_fmaf(-2.0f, d2, p2);
+            vd[(r * 6 + 5) * 64] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
+        }
+    };
+#endif
     // A operand: U4[p / 4][s][kb][lane][p % 4] (16-byte loads, four transform positions each); 36-register ring
     f4 a[9];
     auto aload = [&](int s, int q4) {
@@ -371,7 +414,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
     };
     // one K step = one group of 4 input channels: 36 MFMAs; `chunk` >= 0: request that activation chunk behind the filters.
     // FIRST: the accumulators start from the MFMA's constant-zero C operand (no 144-instruction zero fill per wave)
-    auto kstep = [&](const float* vg, int s, int chunk, auto first, auto with_gload) {
+    auto kstep = [&](const float* vg, int s, int chunk, auto first, auto with_gload, int cprod = -1) {
         constexpr bool FIRST = decltype(first)::value;
         constexpr bool WITH_GLOAD = decltype(with_gload)::value;      // this K step carries the phase's activation request
         __builtin_amdgcn_sched_barrier(0);
@@ -396,6 +439,19 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         f2 bq[BD];
 #define SPRL_BREAD(dst, pr) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(vaddr), "n"(2 * (pr)), "n"(2 * (pr) + 1))
 #define SPRL_BPRE(pr) if constexpr ((pr) < BD) SPRL_BREAD(bq[(pr) % BD], (pr));
+#if SPRL_WINO_INTERLEAVE
+        // the transform's piece (pr >> 1) - (INTERLEAVE - 1) behind filter quad pr >> 1 (the rolling B reads stay BD pairs ahead across it)
+#define SPRL_BPIECE(pr)                                                                                                                \
+        if constexpr (((pr) & 1) && ((pr) >> 1) >= SPRL_WINO_INTERLEAVE - 1 && ((pr) >> 1) < SPRL_WINO_INTERLEAVE + 5) {               \
+            if (WITH_GLOAD && cprod >= 0) {                                                                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                                                     \
+                produce_piece(cprod, std::integral_constant<int, ((pr) >> 1) - (SPRL_WINO_INTERLEAVE - 1)>{});                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                                     \
+            }                                                                                                                          \
+        }
+#else
+#define SPRL_BPIECE(pr)
+#endif
 #define SPRL_BMFMA(p, bv)                                                                                                              \
         if (FIRST) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(p) >> 2][(p) & 3], bv, (f4){ 0.0f, 0.0f, 0.0f, 0.0f }, 0, 0, 0);         \
         else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[(p) >> 2][(p) & 3], bv, acc[p], 0, 0, 0);
@@ -405,11 +461,13 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         SPRL_BMFMA(2 * (pr), bq[(pr) % BD][0])                                                                                        \
         SPRL_BMFMA(2 * (pr) + 1, bq[(pr) % BD][1])                                                                                    \
         if constexpr ((pr) + BD < 18) SPRL_BREAD(bq[(pr) % BD], (pr) + BD);                                                           \
-        if (((pr) & 1) && s + 1 < 16 && !LAB_OFF(6)) aload(s + 1, (pr) >> 1);
+        if (((pr) & 1) && s + 1 < 16 && !LAB_OFF(6)) aload(s + 1, (pr) >> 1);                                                         \
+        SPRL_BPIECE(pr)
         SPRL_BPRE(0) SPRL_BPRE(1) SPRL_BPRE(2) SPRL_BPRE(3) SPRL_BPRE(4) SPRL_BPRE(5) SPRL_BPRE(6) SPRL_BPRE(7)
         SPRL_BSTEP(0) SPRL_BSTEP(1) SPRL_BSTEP(2) SPRL_BSTEP(3) SPRL_BSTEP(4) SPRL_BSTEP(5) SPRL_BSTEP(6) SPRL_BSTEP(7) SPRL_BSTEP(8)
         SPRL_BSTEP(9) SPRL_BSTEP(10) SPRL_BSTEP(11) SPRL_BSTEP(12) SPRL_BSTEP(13) SPRL_BSTEP(14) SPRL_BSTEP(15) SPRL_BSTEP(16) SPRL_BSTEP(17)
 #undef SPRL_BSTEP
+#undef SPRL_BPIECE
 #undef SPRL_BMFMA
 #undef SPRL_BPRE
 #undef SPRL_BREAD
@@ -430,6 +488,18 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
                 else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q4][e], bv, acc[p], 0, 0, 0);
             }
             if (s + 1 < 16 && !LAB_OFF(6)) aload(s + 1, q4);     // (lab bit 6: the filter quads are loaded once and reused)
+#if SPRL_WINO_INTERLEAVE
+            if (WITH_GLOAD && q4 >= SPRL_WINO_INTERLEAVE - 1 && q4 < SPRL_WINO_INTERLEAVE + 5 && cprod >= 0) {      // (wave-uniform; the last phase has no transform)
+                __builtin_amdgcn_sched_barrier(0);
+                if (q4 == SPRL_WINO_INTERLEAVE - 1) produce_piece(cprod, std::integral_constant<int, 0>{});
+                if (q4 == SPRL_WINO_INTERLEAVE) produce_piece(cprod, std::integral_constant<int, 1>{});
+                if (q4 == SPRL_WINO_INTERLEAVE + 1) produce_piece(cprod, std::integral_constant<int, 2>{});
+                if (q4 == SPRL_WINO_INTERLEAVE + 2) produce_piece(cprod, std::integral_constant<int, 3>{});
+                if (q4 == SPRL_WINO_INTERLEAVE + 3) produce_piece(cprod, std::integral_constant<int, 4>{});
+                if (q4 == SPRL_WINO_INTERLEAVE + 4) produce_piece(cprod, std::integral_constant<int, 5>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             if (WITH_GLOAD && ((SPRL_WINO_REQ_POS == 1 && q4 == 4) || (SPRL_WINO_REQ_POS == 2 && q4 == 8))) {
                 __builtin_amdgcn_sched_barrier(0);     // lab: the request in the middle / at the end of the K step
                 gload_to(chunk, pre);
@@ -483,9 +553,9 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
             rload(0);
             rload(1);
         }
-        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{}, std::true_type{});
+        kstep(vs + V_G2, 2 * c + 1, c + 3 < 8 ? c + 3 : -1, std::false_type{}, std::true_type{}, (SPRL_WINO_INTERLEAVE && c + 1 < 8) ? c + 1 : -1);
         LAB_STAMP_LATER(st2_);                         // K step 2c+1 issued
-        if (c + 1 < 8) produce(c + 1);
+        if (!SPRL_WINO_INTERLEAVE && c + 1 < 8) produce(c + 1);
         LAB_STAMP_LATER(st3_);                         // V(c+1) written
         __syncthreads();
         LAB_STAMP_LATER(st4_);                         // barrier passed
