@@ -155,6 +155,9 @@ constexpr int FC_MAXA = 96, FC_LP = 32;
 #ifndef SPRL_WINO_INTERLEAVE
 #define SPRL_WINO_INTERLEAVE 1
 #endif
+#ifndef SPRL_WINO_INTERLEAVE_PLAIN
+#define SPRL_WINO_INTERLEAVE_PLAIN SPRL_WINO_INTERLEAVE      // lab: another first quad for the variants without the residual rows / with the heads
+#endif
 #ifndef SPRL_WINO_WGROUP
 #define SPRL_WINO_WGROUP 0                            // lab: 8x8 kernel on a group-major activation layout (see xvoff)
 #endif
@@ -372,7 +375,8 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         }
     };
 #if SPRL_WINO_INTERLEAVE
-    // lab: the same transform in six PIECES (stage 1 per pair of columns, stage 2 per row) that K step 2c+1 issues between its filter
+    constexpr int ILV0 = (RES && !HEADS) ? SPRL_WINO_INTERLEAVE : SPRL_WINO_INTERLEAVE_PLAIN;      // first piece behind filter quad ILV0 - 1
+    // the same transform in six PIECES (stage 1 per pair of columns, stage 2 per row) that K step 2c+1 issues between its filter
     // quads - the wave's own MFMAs cover its transform, instead of the other wave of the SIMD having to
     f2 wri[3][3];
     auto produce_piece = [&](int c, auto piece_c) {
@@ -442,10 +446,10 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
 #if SPRL_WINO_INTERLEAVE
         // the transform's piece (pr >> 1) - (INTERLEAVE - 1) behind filter quad pr >> 1 (the rolling B reads stay BD pairs ahead across it)
 #define SPRL_BPIECE(pr)                                                                                                                \
-        if constexpr (((pr) & 1) && ((pr) >> 1) >= SPRL_WINO_INTERLEAVE - 1 && ((pr) >> 1) < SPRL_WINO_INTERLEAVE + 5) {               \
+        if constexpr (((pr) & 1) && ((pr) >> 1) >= ILV0 - 1 && ((pr) >> 1) < ILV0 + 5) {                                               \
             if (WITH_GLOAD && cprod >= 0) {                                                                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                                                     \
-                produce_piece(cprod, std::integral_constant<int, ((pr) >> 1) - (SPRL_WINO_INTERLEAVE - 1)>{});                          \
+                produce_piece(cprod, std::integral_constant<int, ((pr) >> 1) - (ILV0 - 1)>{});                                          \
                 __builtin_amdgcn_sched_barrier(0);                                                                                     \
             }                                                                                                                          \
         }
