@@ -145,6 +145,9 @@ constexpr int FC_MAXA = 96, FC_LP = 32;
 #ifndef SPRL_WINO_ST_AUX
 #define SPRL_WINO_ST_AUX 2                            // ... and of its output stores (default policy for either: -1.3 / -2.9 % in the bench, profiles/r04zo_*)
 #endif
+#ifndef SPRL_WINO_F4_INTERLEAVE
+#define SPRL_WINO_F4_INTERLEAVE 0                     // lab: F(4x4) any-board kernel - the transform in pieces behind the filter quads of K step 2c+1 (first quad n - 1)
+#endif
 #ifndef SPRL_WINO_F4_REQ_HEAD
 #define SPRL_WINO_F4_REQ_HEAD 0                       // F(4x4) any-board kernel: the activation request at the head of the phase (0: behind the transform)
 #endif
@@ -1206,12 +1209,48 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
             }
         }
     };
+    // F(4x4), lab (SPRL_WINO_F4_INTERLEAVE): the transform in six pieces issued behind filter quads of K step 2c+1 (see the 8x8 kernel)
+    f2 wri4[3][3];
+    auto produce_piece = [&](int c, auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value;
+        if constexpr (M == 4) {
+            const float* pp = in_buf + (c & 1) * IN_BUF + patch0;
+            float* vd = v_buf + (c & 1) * 2 * VG + vdst0;
+            if constexpr (piece < 3) {
+                constexpr int jp = piece, j = 2 * jp;
+                const f2 e0 = { pp[j], pp[j + 1] }, e1 = { pp[6 + j], pp[7 + j] }, e2 = { pp[12 + j], pp[13 + j] },
+                         e3 = { pp[18 + j], pp[19 + j] }, e4 = { pp[24 + j], pp[25 + j] };
+                if (wa == 0) {
+                    const f2 p = e4 - 4.0f * e2, q = e3 - 4.0f * e1;
+                    wri4[0][jp] = (4.0f * e0 + e4) - 5.0f * e2;
+                    wri4[1][jp] = p + q;
+                    wri4[2][jp] = p - q;
+                } else {
+                    const f2 p = e3 - e1, d = e2 - e0;
+                    wri4[0][jp] = p + 2.0f * d;
+                    wri4[1][jp] = p - 2.0f * d;
+                    wri4[2][jp] = (4.0f * e0 + e4) - 5.0f * e2;
+                }
+            } else {
+                constexpr int r = piece - 3;
+                const float w0 = wri4[r][0][0], w1 = wri4[r][0][1], w2 = wri4[r][1][0], w3 = wri4[r][1][1], w4 = wri4[r][2][0], w5 = wri4[r][2][1];
+                const float p = __builtin_fmaf(-4.0f, w2, w4), q = __builtin_fmaf(-4.0f, w1, w3), p2 = w4 - w2, d2 = w3 - w1;
+                vd[(r * 6 + 0) * 64] = __builtin_fmaf(-5.0f, w2, __builtin_fmaf(4.0f, w0, w4));
+                vd[(r * 6 + 1) * 64] = p + q;
+                vd[(r * 6 + 2) * 64] = p - q;
+                vd[(r * 6 + 3) * 64] = __builtin_fmaf(2.0f, d2, p2);
+                vd[(r * 6 + 4) * 64] = __builtin_fmaf(-2.0f, d2, p2);
+                vd[(r * 6 + 5) * 64] = __builtin_fmaf(-5.0f, w3, __builtin_fmaf(4.0f, w1, w5));
+            }
+        }
+    };
+    constexpr bool F4_ILV = M == 4 && LAY == 1 && SPRL_WINO_F4_INTERLEAVE > 0 && SPRL_WINO_BROLL_F4 > 0;
     const f4* ua = (const f4*)u + kb * 64 + lane;
     f4 a0[NQ], a1[DEEP ? NQ : 1];                     // filter quads of the even / odd K steps (one ring unless DEEP)
     auto aload = [&](int s, int k, f4* a) { a[k] = ua[(size_t)k * (16 * 4 * 64) + s * 256]; };
     // one K step (group of 4 input channels): NP MFMAs from ring `a`; FIRST: the accumulators start from the constant-zero C
     // operand; behind each quad's MFMAs the quad of K step s + AHEAD is requested into the same ring
-    auto kstep = [&](const float* vg, int s, auto first, f4* a) {
+    auto kstep = [&](const float* vg, int s, auto first, f4* a, int cprod = -1) {
         constexpr bool FIRST = decltype(first)::value;
         constexpr int AHEAD = DEEP ? 2 : 1;
         if (!FIRST && LAB_OFF(3)) return;              // lab: only the first K step (no MFMA loop)
@@ -1236,6 +1275,13 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
                 SPRL_BMFMA(2 * (pr) + 1, bq[(pr) % BD][1])                                                                            \
                 if constexpr ((pr) + BD < NPR) { SPRL_BREAD(bq[(pr) % BD], (pr) + BD) }                                               \
                 if ((((pr) & 1) || 2 * (pr) + 2 >= NP) && s + AHEAD < 16) aload(s + AHEAD, (pr) >> 1, a);                             \
+                if constexpr (F4_ILV && ((pr) & 1) && ((pr) >> 1) >= SPRL_WINO_F4_INTERLEAVE - 1 && ((pr) >> 1) < SPRL_WINO_F4_INTERLEAVE + 5) { \
+                    if (cprod >= 0) {                                                                                                  \
+                        __builtin_amdgcn_sched_barrier(0);                                                                             \
+                        produce_piece(cprod, std::integral_constant<int, (F4_ILV ? ((pr) >> 1) - (SPRL_WINO_F4_INTERLEAVE - 1) : 0)>{}); \
+                        __builtin_amdgcn_sched_barrier(0);                                                                             \
+                    }                                                                                                                  \
+                }                                                                                                                      \
             }
             SPRL_BPRE(0) SPRL_BPRE(1) SPRL_BPRE(2) SPRL_BPRE(3) SPRL_BPRE(4) SPRL_BPRE(5) SPRL_BPRE(6) SPRL_BPRE(7)
             SPRL_BSTEP(0) SPRL_BSTEP(1) SPRL_BSTEP(2) SPRL_BSTEP(3) SPRL_BSTEP(4) SPRL_BSTEP(5) SPRL_BSTEP(6) SPRL_BSTEP(7) SPRL_BSTEP(8)
@@ -1289,10 +1335,10 @@ __global__ void __launch_bounds__(NTHR2, OCC) wino_conv64_nchw_kernel(const floa
             gload(c + 3 < 8 ? c + 3 : -1, pre);
             __builtin_amdgcn_sched_barrier(0);
         }
-        kstep(vs + VG, 2 * c + 1, std::false_type{}, DEEP ? a1 : a0);
+        kstep(vs + VG, 2 * c + 1, std::false_type{}, DEEP ? a1 : a0, (F4_ILV && c + 1 < 8) ? c + 1 : -1);
         __builtin_amdgcn_sched_barrier(0);
         if (EARLY_RES && DEEP && c == 6) early_res();
-        if (c + 1 < 8) produce(c + 1);
+        if (!F4_ILV && c + 1 < 8) produce(c + 1);
         if constexpr (!REQ_HEAD) {
             if (c + 2 < 8) lstore(in_buf + (c & 1) * IN_BUF, pre);
             if (LAY == 1 && !SPRL_WINO_GLOAD_BRANCH) gload(c + (DEEP_ACT ? 4 : 3) < 8 ? c + (DEEP_ACT ? 4 : 3) : -1, pre);      // unconditional (see gload)
