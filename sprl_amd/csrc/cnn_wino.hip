@@ -469,7 +469,12 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
         SPRL_BMFMA(2 * (pr) + 1, bq[(pr) % BD][1])                                                                                    \
         if constexpr ((pr) + BD < 18) SPRL_BREAD(bq[(pr) % BD], (pr) + BD);                                                           \
         if (((pr) & 1) && s + 1 < 16 && !LAB_OFF(6)) aload(s + 1, (pr) >> 1);                                                         \
-        SPRL_BPIECE(pr)
+        SPRL_BPIECE(pr)                                                                                                                \
+        if constexpr (WITH_GLOAD && ((SPRL_WINO_REQ_POS == 1 && (pr) == 9) || (SPRL_WINO_REQ_POS == 2 && (pr) == 17))) {               \
+            __builtin_amdgcn_sched_barrier(0);         /* lab: the request in the middle / at the end of the K step */                 \
+            gload_to(chunk, pre);                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        }
         SPRL_BPRE(0) SPRL_BPRE(1) SPRL_BPRE(2) SPRL_BPRE(3) SPRL_BPRE(4) SPRL_BPRE(5) SPRL_BPRE(6) SPRL_BPRE(7)
         SPRL_BSTEP(0) SPRL_BSTEP(1) SPRL_BSTEP(2) SPRL_BSTEP(3) SPRL_BSTEP(4) SPRL_BSTEP(5) SPRL_BSTEP(6) SPRL_BSTEP(7) SPRL_BSTEP(8)
         SPRL_BSTEP(9) SPRL_BSTEP(10) SPRL_BSTEP(11) SPRL_BSTEP(12) SPRL_BSTEP(13) SPRL_BSTEP(14) SPRL_BSTEP(15) SPRL_BSTEP(16) SPRL_BSTEP(17)
