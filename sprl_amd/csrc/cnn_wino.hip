@@ -585,6 +585,7 @@ __global__ void __launch_bounds__(NTHR2, 2) wino_conv64_kernel(const float* x, c
 
     if constexpr (STEM) {
         // ---- the stem of this workgroup's four boards: wave w = board n0 + w (see StemArgs) ----
+        static_assert(!SPRL_WINO_WGROUP, "the group-major lab layout is wired into the plain / residual variants only");
         // The filter quads of K step 0 are requested first and arrive under the stem; channels 0..15 of the stem output ARE the
         // activation chunks 0 and 1 (groups 0..3), so they go straight into the two LDS images as well - the K loop's first V is
         // built from them without a trip to memory; the chunks from 2 on are read back from x0 (L2) behind the drain + barrier.
